@@ -1,0 +1,161 @@
+/* libogg_hip.so -- C ABI of the MI355X (gfx950) supergrid hot path.
+ *
+ * The reference (nikizadehgfdl/ocean_model_grid_generator, ocean_grid_generator.py, cited as OGG:<line>) has no
+ * FFI: its boundary is the set of Python call sites in main() (OGG:1004-1170).  Each entry point below replaces
+ * one of those callees; the Python host (ocean_model_grid_generator_amd/ocean_grid_generator.py) binds them
+ * with ctypes under the reference's own function names.
+ *
+ * Conventions
+ *   - all arrays are fp64, C order [j][i], i fastest, densely packed; sizes are given per argument;
+ *   - entry points WITHOUT the _dev suffix take HOST pointers (caller-allocated, caller-owned; the library
+ *     stages through device memory it allocates and frees inside the call);
+ *   - entry points WITH the _dev suffix take DEVICE pointers and a hipStream_t (passed as void*), enqueue
+ *     work and return without synchronising; no allocation, no host sync (graph-capturable);
+ *   - every function returns OGG_OK or an error code; ogg_last_error() gives the text (thread-local);
+ *   - no C++ exception crosses this boundary; calls may come from any thread, one call at a time per stream.
+ */
+#ifndef OGG_HIP_H
+#define OGG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OGG_OK 0
+#define OGG_EORDER 1 /* "Uncoded order" (OGG:204,222,255) / "order not coded" (OGG:547,562) */
+#define OGG_ESHAPE 2 /* "Input arrays do not have the same shape!" (OGG:722) and other size errors */
+#define OGG_EHIP 3   /* a HIP runtime call failed (no device, launch failure, ...) */
+#define OGG_ENOMEM 4 /* device allocation failed */
+#define OGG_EARG 5   /* null pointer / invalid scalar */
+
+const char* ogg_last_error(void);
+const char* ogg_version(void);
+int ogg_device_count(int* count);
+int ogg_set_device(int device);
+int ogg_device_name(char* buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Mercator / regular lat-lon builders
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* y_mercator_rounded (OGG:309-311, with y_mercator OGG:292-295): y* = sign(y)*round_half_even(|y|),
+ * y = R*log((1+sin(phi))/cos(phi)), R = Ni/(2*pi).  phi in radians.  ystar: int64[n]. */
+int ogg_y_mercator_rounded(long Ni, long n, const double* phi_rad, long long* ystar);
+int ogg_y_mercator_rounded_dev(long Ni, long n, const double* phi_rad, long long* ystar, void* stream);
+
+/* phi_mercator (OGG:298-301): phi = atan(sinh(y/R))*(180/pi), degrees, for arbitrary ordinates y[n]. */
+int ogg_phi_mercator(long Ni, long n, const double* y, double* phi_deg);
+int ogg_phi_mercator_dev(long Ni, long n, const double* y, double* phi_deg, void* stream);
+/* same for the integer ordinates y0, y0+1, ..., y0+n-1 (the axis of OGG:336), no input array */
+int ogg_mercator_axis_dev(long Ni, long long y0, long n, double* phi_deg, void* stream);
+
+/* out[k] = a0 + (k*len)/denom, k = 0..n-1: the axes of OGG:113,115,431,834,835 */
+int ogg_linear_axis_dev(long n, double a0, double len, double denom, double* out, void* stream);
+
+/* np.tile pair (OGG:430-432, OGG:840-841): x[j][i] = lon1d[i], y[j][i] = lat1d[j]; rows j0..j0+nrows-1 of the
+ * lat axis are written to nrows x ni1 outputs. */
+int ogg_tile_latlon(long nrows, long ni1, const double* lat1d, const double* lon1d, double* x, double* y);
+int ogg_tile_latlon_dev(long nrows, long ni1, const double* lat1d, const double* lon1d, double* x, double* y,
+                        void* stream);
+
+/* generate_latlon_grid (OGG:832-846) incl. both axes; skip_first_row=1 reproduces the ensure_nj_even row drop
+ * (OGG:836-838).  x, y: (lnj+1-skip_first_row) x (lni+1). */
+int ogg_generate_latlon_grid(long lni, long lnj, double llon0, double llen_lon, double llat0, double llen_lat,
+                             int skip_first_row, double* x, double* y);
+
+/* ------------------------------------------------------------------------------------------------------
+ * MIDAS stencil metrics (OGG:687-716) and grid orientation angle (OGG:719-729), fused
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* x, y: nrows_xy x ni1 point rows.  Writes
+ *   dx    [n_pt_rows  ][ni1-1]   (rows 0..n_pt_rows-1)            if dx    != NULL
+ *   angle [n_pt_rows  ][ni1  ]                                     if angle != NULL
+ *   dy    [n_cell_rows][ni1  ]   (needs point row j+1: n_cell_rows+1 <= nrows_xy)   if dy != NULL
+ *   area  [n_cell_rows][ni1-1]                                     if area  != NULL
+ * A full sub-grid has n_pt_rows = nrows_xy = nj+1, n_cell_rows = nj.  A latitude band passes its own rows plus one
+ * halo row (the first row of the band above) and n_pt_rows = n_cell_rows = nrows_xy-1. */
+int ogg_grid_metrics_midas_dev(long nrows_xy, long ni1, const double* x, const double* y, long n_pt_rows,
+                               long n_cell_rows, double Re, int latlon_areafix, double* dx, double* dy,
+                               double* area, double* angle, void* stream);
+/* generate_grid_metrics_MIDAS(x, y, Re, latlon_areafix): dx (nj1 x ni1-1), dy (nj1-1 x ni1), area (nj1-1 x ni1-1) */
+int ogg_grid_metrics_midas(long nj1, long ni1, const double* x, const double* y, double Re, int latlon_areafix,
+                           double* dx, double* dy, double* area);
+/* angle_x(x, y): angle_dx (nj1 x ni1), degrees */
+int ogg_angle_x(long nj1, long ni1, const double* x, const double* y, double* angle_dx);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Murray bipolar Arctic cap
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* bipolar_projection (OGG:33-100), element-wise over n points.  metrics_only != 0: lams, phis may be NULL. */
+int ogg_bipolar_projection(long n, const double* lamg, const double* phig, double lon_bp, double rp,
+                           int metrics_only, double* lams, double* phis, double* h_i_inv, double* h_j_inv);
+int ogg_bipolar_projection_dev(long n, const double* lamg, const double* phig, double lon_bp, double rp,
+                               int metrics_only, double* lams, double* phis, double* h_i_inv, double* h_j_inv,
+                               void* stream);
+
+/* generate_bipolar_cap_mesh (OGG:103-122), rows j0..j0+nrows-1 of the (Nj+1) x (Ni+1) mesh.
+ * lams, phis: nrows x (Ni+1).  h_i_inv: nrows x Ni and h_j_inv: nrows x (Ni+1), already scaled as OGG:119-120
+ * (h_j_inv row Nj is computed but dropped by the reference; rows >= Nj are not written); either may be NULL. */
+int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
+                             double* phis, double* h_i_inv, double* h_j_inv, void* stream);
+int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis,
+                         double* h_i_inv, double* h_j_inv);
+
+/* bipolar_cap_metrics_quad_fast (OGG:136-188): Gauss-Lobatto quadrature (order 2..5) of the analytic scale
+ * factors.  Band form: dxq rows j0..j0+n_dx_rows-1 of (ny+1) x nx; dyq rows j0..j0+n_cell_rows-1 of ny x (nx+1);
+ * daq rows j0..j0+n_cell_rows-1 of ny x nx. */
+int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp,
+                                     double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
+                                     double* daq, void* stream);
+int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                 double* dxq, double* dyq, double* daq);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Displaced-pole Southern cap
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* displacedPoleCap_mesh (OGG:488-506) at index vectors i[n_i], j[n_j] (may be fractional), including the
+ * sequential 360-degree unwrap along i (monotonic_bounding, OGG:470-475).  lams, phis: n_j x n_i. */
+int ogg_displaced_pole_mesh_dev(long n_i, const double* i, long n_j, const double* j, long ni, long nj, double lon0,
+                                double lat0, double lam_pole, double r_pole, double* lams, double* phis,
+                                void* stream);
+int ogg_displaced_pole_mesh(long n_i, const double* i, long n_j, const double* j, long ni, long nj, double lon0,
+                            double lat0, double lam_pole, double r_pole, double* lams, double* phis);
+/* generate_displaced_pole_grid (OGG:509-518), rows j0..j0+nrows-1 of (Nj+1) x (Ni+1). */
+int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0,
+                                long nrows, double* x, double* y, void* stream);
+
+/* numerical_hi / numerical_hj (OGG:535-562; great_arc_distance OGG:522-532) on the lattice j[n_j] x i[n_i].
+ * fd_order in {2,4,6}.  h_i, h_j: n_j x n_i (either may be NULL). */
+int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, const double* j, long nx, long ny,
+                                       double lon0, double lat0, double lon_dp, double r_dp, double eps,
+                                       int fd_order, double* h_i, double* h_j, void* stream);
+int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const double* j, long nx, long ny,
+                                   double lon0, double lat0, double lon_dp, double r_dp, double eps, int fd_order,
+                                   double* h_i, double* h_j);
+
+/* displacedPoleCap_metrics_quad (OGG:565-601): quadrature order (2..5) is also the finite-difference order, as in
+ * the reference (OGG:583-584), so only orders 2 and 4 are valid.  Band form as for the bipolar cap; cell rows
+ * below j0 are simply not evaluated (main() discards the doughnut rows, OGG:1177-1186). */
+int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                        double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
+                                        double* dxq, double* dyq, double* daq, void* stream);
+int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                    double Re, double* dxq, double* dyq, double* daq);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Device utilities used by the band-sharded pipeline (bench / multi-GPU)
+ * ---------------------------------------------------------------------------------------------------- */
+int ogg_fill_dev(long n, double value, double* out, void* stream);
+/* per-launch timing of the dominant kernels with HIP events on the given stream: start/stop bracket */
+int ogg_event_create(void** ev);
+int ogg_event_destroy(void* ev);
+int ogg_event_record(void* ev, void* stream);
+int ogg_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int ogg_stream_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGG_HIP_H */

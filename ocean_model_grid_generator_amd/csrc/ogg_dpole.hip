@@ -1,0 +1,454 @@
+// K5 / K6: displaced-pole Southern cap.
+//   displacedPoleCap_projection / _mesh      OGG:447-506   (generate_displaced_pole_grid OGG:509-518)
+//   monotonic_bounding                       OGG:470-475
+//   great_arc_distance, numerical_hi/hj      OGG:522-562
+//   displacedPoleCap_metrics_quad            OGG:565-601
+//
+// One templated row-sweep kernel serves three uses:
+//   MESH  (F = 0)      lam, phi on a lattice of (fractional) indices          -> K5
+//   EMIT  (F = 2,4,6)  finite-difference scale factors h_i, h_j on a lattice   -> numerical_hi / numerical_hj
+//   QUAD  (F = N)      Lobatto quadrature of h_i, h_j, h_i*h_j per cell        -> K6
+//
+// monotonic_bounding is a sequential scan along i: column k is lowered by 360 iff v_k - x_{k-1} > 100 where x_{k-1}
+// is the ALREADY ADJUSTED previous column.  With s_k in {0,1} the "was lowered" state, s_k = f_k(s_{k-1}) with
+// f_k(0) = [v_k - v_{k-1} > 100], f_k(1) = [v_k - (v_{k-1} - 360) > 100] -- a composition of 1-bit maps, which is
+// associative.  A workgroup sweeps a lattice row in chunks of SW_TX columns; inside a chunk the maps of all probes
+// (bit-packed, one bit per probe) are composed with a wave64 shuffle scan plus a 4-entry LDS carry, and the state and
+// raw value of the last column are carried to the next chunk.  The comparison values are formed exactly as the
+// reference forms them, so the unwrap is bit-faithful to the sequential loop.
+//
+// K6 is fp64-VALU bound.  Everything that depends on the column only (sincos of the longitude, the first Moebius map)
+// is evaluated once per column and reused by the N lattice rows of the cell row; everything that depends on the row
+// only (the gnomonic radius) once per workgroup.  Duplicate Lobatto nodes on shared vertical cell edges are evaluated
+// once: a repeated column has v_k == v_{k-1}, whose map is the identity, so skipping it leaves every state unchanged.
+#include "ogg_common.h"
+#include "ogg_math.h"
+
+namespace ogg {
+QuadNodes quad_nodes_host(int order);
+}
+
+namespace {
+
+using namespace ogg;
+
+constexpr int SW_TX = 256;
+constexpr int SW_WAVES = SW_TX / 64;
+constexpr int MODE_MESH = 0, MODE_EMIT = 1, MODE_QUAD = 2;
+
+struct SweepParams {
+    // geometry of the cap (OGG:478-495)
+    long ni, nj;
+    double lon0, lat0, lam_pole, r_pole;
+    double eps, Re;
+    // lattice
+    long n_cols;          // columns per lattice row (MESH/EMIT: n_i; QUAD: unique columns M*nx+1)
+    long n_rows;          // MESH/EMIT: lattice rows; QUAD: cell rows handled by this launch
+    const double* i_arr;  // MESH/EMIT: column indices or NULL for 0,1,2,...
+    const double* j_arr;  // MESH/EMIT: row indices or NULL for j0, j0+1, ...
+    long j0;              // first row (MESH iota) / first cell row of the band (QUAD)
+    long nx, ny;          // QUAD: cells
+    int top_row;          // QUAD: 1 = only dxq[ny][:]
+    long out_row;         // QUAD top_row: band-local output row
+    QuadNodes q;
+    // outputs
+    double* out0;  // MESH lam | EMIT h_i | QUAD dxq
+    double* out1;  // MESH phi | EMIT h_j | QUAD dyq
+    double* out2;  //                      QUAD daq
+};
+
+struct DpConst {
+    double z0r, z0i, r_joint;
+};
+
+OGG_DEV DpConst dp_const(const SweepParams& p) {
+    DpConst c;
+    c.r_joint = tan((90 + p.lat0) * kPi180);  // OGG:494
+    double s, co;
+    sincos(p.lam_pole * kPi180, &s, &co);
+    c.z0r = p.r_pole * co;                    // OGG:495
+    c.z0i = p.r_pole * s;
+    return c;
+}
+
+// column-only part of OGG:451-452: e' = (e - z0) / (1 - conj(z0) e)
+OGG_DEV cplx dp_column(double iv, const SweepParams& p, const DpConst& c) {
+    const double lon = p.lon0 + (iv * 360.0) / (double)p.ni;  // OGG:479
+    double s, co;
+    sincos(lon * kPi180, &s, &co);
+    const cplx e = {co, s};
+    const cplx num = {e.re - c.z0r, e.im - c.z0i};
+    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, e);
+    const cplx den = {1.0 - cz.re, 0.0 - cz.im};
+    return cdiv(num, den);
+}
+
+// row-only part of OGG:448: r = tan((90+lat) PI/180) / r_joint
+OGG_DEV double dp_row_radius(double jv, const SweepParams& p, const DpConst& c) {
+    const double lat = -90.0 + (jv * (p.lat0 - (-90.0))) / (double)p.nj;  // OGG:480-482
+    return tan((90 + lat) * kPi180) / c.r_joint;
+}
+
+// per-point remainder of OGG:454-466: raw longitude (before the unwrap) and latitude
+OGG_DEV void dp_point(double r, cplx ep, const DpConst& c, double& lam_raw, double& phi) {
+    const cplx z = {r * ep.re, r * ep.im};
+    const cplx num = {z.re + c.z0r, z.im + c.z0i};
+    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, z);
+    const cplx den = {1 + cz.re, cz.im};
+    const cplx w = cdiv(num, den);
+    lam_raw = atan2(w.im, w.re) * k180Pi;  // np.angle(deg=True)
+    const double rw = cabs_np(w);
+    phi = -90 + atan(rw * c.r_joint) / kPi180;
+}
+
+// OGG:527-532 for point0 = (lam0, phi0), point1 = (lam1, phi1) in degrees
+OGG_DEV double great_arc(double lam0d, double phi0d, double lam1d, double phi1d) {
+    const double lam0 = lam0d * kPi180, phi0 = phi0d * kPi180;
+    const double lam1 = lam1d * kPi180, phi1 = phi1d * kPi180;
+    const double dphi = phi1 - phi0, dlam = lam1 - lam0;
+    const double sp = sin(0.5 * dphi), sl = sin(0.5 * dlam);
+    const double d = sp * sp + sl * sl * cos(phi0) * cos(phi1);
+    return 2.0 * asin(sqrt(d));
+}
+
+template <int F>
+OGG_DEV double central_difference(const double* ds, double reps) {  // OGG:539-546
+    if (F == 2) return 0.5 * ds[0] * reps;
+    if (F == 4) return (8.0 * ds[0] - ds[1]) * (1.0 / 12.0) * reps;
+    return (45.0 * ds[0] - 9.0 * ds[1] + ds[2]) * (1.0 / 60.0) * reps;
+}
+
+template <int N>
+OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
+    if (N == 1) return y[0];
+    if (N == 2) return (1.0 / 2.0) * (y[0] + y[1]);
+    if (N == 3) return (1.0 / 6.0) * (4.0 * y[1] + (y[0] + y[2]));
+    if (N == 4) return (1.0 / 12.0) * (5.0 * (y[1] + y[2]) + (y[0] + y[3]));
+    return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
+}
+
+// F: finite-difference order (0 for MESH).  N: lattice rows per workgroup (quadrature order for QUAD, 1 otherwise).
+template <int F, int N, int MODE>
+__global__ __launch_bounds__(SW_TX) void dpole_sweep_kernel(SweepParams p) {
+    constexpr int H = F / 2;                        // probe distances 1..H (in units of eps)
+    constexpr int HH = (H > 0) ? H : 1;
+    constexpr int NP = (MODE == MODE_MESH) ? 1 : 2 * F;  // probes per lattice point: H x {+,-} x {i, j}
+    constexpr int NV = (MODE == MODE_MESH) ? 1 : 1 + F;  // distinct column (and row) variants: base, +-m*eps
+    constexpr int M = (N > 1) ? N - 1 : 1;          // unique columns per cell (QUAD)
+    constexpr unsigned ALL = (NP >= 32) ? 0xffffffffu : ((1u << NP) - 1u);
+    constexpr int STEP = (MODE == MODE_QUAD) ? (255 / M) * M : SW_TX;  // new columns per chunk
+    constexpr int CELLS = STEP / M;                 // QUAD: cells per chunk
+
+    __shared__ double s_v[NP][SW_TX];
+    __shared__ double s_carry_v[N][NP];
+    __shared__ unsigned s_carry_state[N];
+    __shared__ unsigned s_w0[SW_WAVES], s_w1[SW_WAVES];
+    __shared__ double s_r[N][NV];
+    __shared__ double s_h[(MODE == MODE_QUAD) ? 2 * N : 1][SW_TX];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const DpConst c = dp_const(p);
+    const double reps = 1.0 / p.eps;
+    const long row = blockIdx.x;  // lattice row (MESH/EMIT) or band-local cell row (QUAD)
+    const long cell_row = (MODE == MODE_QUAD) ? (p.top_row ? p.ny : p.j0 + row) : 0;
+    const int n_kk = (MODE == MODE_QUAD) ? (p.top_row ? 1 : N) : 1;
+
+    // row-only quantities: gnomonic radius of the base row and of the rows displaced by +-m*eps (variant order:
+    // 0 = base, 2m-1 = +m*eps, 2m = -m*eps)
+    if (tid < N * NV) {
+        const int kk = tid / NV, var = tid % NV;
+        if (kk < n_kk) {
+            double jv;
+            if (MODE == MODE_QUAD)
+                jv = lattice_node(p.q, kk, cell_row);
+            else
+                jv = p.j_arr ? p.j_arr[row] : (double)(p.j0 + row);
+            if (var > 0) {
+                const double off = (double)((var + 1) / 2) * p.eps;
+                jv = (var & 1) ? jv + off : jv - off;
+            }
+            s_r[kk][var] = dp_row_radius(jv, p, c);
+        }
+    }
+    // index of the first column of the row, for the seed lon_grid[0,0] (OGG:463)
+    double i_first;
+    if (MODE == MODE_QUAD)
+        i_first = lattice_node(p.q, 0, 0);
+    else
+        i_first = p.i_arr ? p.i_arr[0] : 0.0;
+    __syncthreads();
+
+    for (long c0 = 0; c0 < p.n_cols; c0 += STEP) {
+        if (MODE == MODE_QUAD && c0 > 0 && c0 + 1 >= p.n_cols) break;  // only the overlap column is left
+        const long g = c0 + tid;  // global column
+        const bool active = (g < p.n_cols) && (MODE != MODE_QUAD || tid <= STEP);
+        // column-only quantities for the NV column variants
+        cplx ep[NV];
+        if (active) {
+            double iv;
+            if (MODE == MODE_QUAD)
+                iv = lattice_node(p.q, (int)(g % M), g / M);
+            else
+                iv = p.i_arr ? p.i_arr[g] : (double)g;
+            ep[0] = dp_column(iv, p, c);
+#pragma unroll
+            for (int m = 1; m <= H; ++m) {
+                const double off = (double)m * p.eps;
+                ep[2 * m - 1] = dp_column(iv + off, p, c);
+                ep[2 * m] = dp_column(iv - off, p, c);
+            }
+        }
+        // last thread whose state/raw values seed the next chunk
+        const int carry_tid = (MODE == MODE_QUAD) ? STEP - 1 : SW_TX - 1;
+
+#pragma unroll 1
+        for (int kk = 0; kk < n_kk; ++kk) {
+            // probe order: [2(m-1)] = (j, i+m eps), [2(m-1)+1] = (j, i-m eps), then F + the same for (j+-m eps, i)
+            double v[NP], ph[NP];
+            if (active) {
+                if constexpr (MODE == MODE_MESH) {
+                    dp_point(s_r[kk][0], ep[0], c, v[0], ph[0]);
+                } else {
+#pragma unroll
+                    for (int m = 1; m <= H; ++m) {
+                        dp_point(s_r[kk][0], ep[2 * m - 1], c, v[2 * (m - 1)], ph[2 * (m - 1)]);
+                        dp_point(s_r[kk][0], ep[2 * m], c, v[2 * (m - 1) + 1], ph[2 * (m - 1) + 1]);
+                        dp_point(s_r[kk][2 * m - 1], ep[0], c, v[F + 2 * (m - 1)], ph[F + 2 * (m - 1)]);
+                        dp_point(s_r[kk][2 * m], ep[0], c, v[F + 2 * (m - 1) + 1], ph[F + 2 * (m - 1) + 1]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) v[q] = 0.0, ph[q] = 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) s_v[q][tid] = v[q];
+            const unsigned carry_state = s_carry_state[kk];  // read before anybody rewrites it below
+            __syncthreads();
+
+            // 1-bit maps f(0), f(1) of every probe, packed
+            unsigned f0 = 0u, f1 = ALL;  // identity
+            if (active) {
+                f0 = 0u;
+                f1 = 0u;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    bool b0, b1;
+                    if (g == 0) {
+                        // first column: compared with the seed, independent of any state
+                        double di = 0.0;
+                        if (MODE != MODE_MESH && q < F) {
+                            const double off = (double)(q / 2 + 1) * p.eps;
+                            di = (q & 1) ? -off : off;
+                        }
+                        const double seed = p.lon0 + ((i_first + di) * 360.0) / (double)p.ni;
+                        b0 = b1 = (v[q] - seed > 100);
+                    } else {
+                        const double vp = (tid > 0) ? s_v[q][tid - 1] : s_carry_v[kk][q];
+                        b0 = (v[q] - vp > 100);
+                        b1 = (v[q] - (vp - 360) > 100);
+                    }
+                    f0 |= (b0 ? 1u : 0u) << q;
+                    f1 |= (b1 ? 1u : 0u) << q;
+                }
+            }
+            // inclusive wave scan of the composition (later o earlier)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned e0 = __shfl_up(f0, off);
+                const unsigned e1 = __shfl_up(f1, off);
+                if (lane >= off) {
+                    const unsigned h0 = (e0 & f1) | (~e0 & f0);
+                    const unsigned h1 = (e1 & f1) | (~e1 & f0);
+                    f0 = h0;
+                    f1 = h1;
+                }
+            }
+            if (lane == 63) {
+                s_w0[wave] = f0;
+                s_w1[wave] = f1;
+            }
+            __syncthreads();
+            unsigned st = carry_state;
+            for (int w = 0; w < wave; ++w) st = (st & s_w1[w]) | (~st & s_w0[w]);
+            st = ((st & f1) | (~st & f0)) & ALL;  // state of this column, all probes
+
+            if (active && tid == carry_tid) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) s_carry_v[kk][q] = v[q];
+                s_carry_state[kk] = st;
+            }
+            // OGG:473: lower by 360 where flagged
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if ((st >> q) & 1u) v[q] = v[q] - 360;
+
+            if constexpr (MODE == MODE_MESH) {
+                if (active) {
+                    p.out0[row * p.n_cols + g] = v[0];
+                    p.out1[row * p.n_cols + g] = ph[0];
+                }
+            } else {
+                double hi = 0.0, hj = 0.0;
+                if (active) {
+                    double dsi[HH], dsj[HH];
+#pragma unroll
+                    for (int m = 0; m < H; ++m) {
+                        dsi[m] = great_arc(v[2 * m], ph[2 * m], v[2 * m + 1], ph[2 * m + 1]);
+                        dsj[m] = great_arc(v[F + 2 * m], ph[F + 2 * m], v[F + 2 * m + 1], ph[F + 2 * m + 1]);
+                    }
+                    hi = central_difference<F>(dsi, reps);
+                    hj = central_difference<F>(dsj, reps);
+                }
+                if constexpr (MODE == MODE_EMIT) {
+                    if (active) {
+                        if (p.out0) p.out0[row * p.n_cols + g] = hi;
+                        if (p.out1) p.out1[row * p.n_cols + g] = hj;
+                    }
+                } else {
+                    s_h[2 * kk][tid] = hi;
+                    s_h[2 * kk + 1][tid] = hj;
+                }
+            }
+        }  // kk
+
+        if constexpr (MODE == MODE_QUAD) {
+            __syncthreads();
+            // one thread per cell of the chunk, reference summation order (OGG:593-595, 597-599)
+            const long ci = c0 / M + tid;
+            if (tid < CELLS && ci < p.nx) {
+                const int l0 = M * tid;
+                double yv[N];
+#pragma unroll
+                for (int ii = 0; ii < N; ++ii) yv[ii] = s_h[0][l0 + ii];
+                const long orow = p.top_row ? p.out_row : row;
+                p.out0[orow * p.nx + ci] = qavg_1d<N>(yv) * p.Re;
+                if (!p.top_row) {
+#pragma unroll
+                    for (int jj = 0; jj < N; ++jj) yv[jj] = s_h[2 * jj + 1][l0];
+                    p.out1[row * (p.nx + 1) + ci] = qavg_1d<N>(yv) * p.Re;
+                    if (ci == p.nx - 1) {
+#pragma unroll
+                        for (int jj = 0; jj < N; ++jj) yv[jj] = s_h[2 * jj + 1][l0 + M];
+                        p.out1[row * (p.nx + 1) + p.nx] = qavg_1d<N>(yv) * p.Re;
+                    }
+                    double da;
+                    if (N == 2) {
+                        const double d = 1.0 / 2.0;
+                        da = d * d * (s_h[0][l0] * s_h[1][l0] + s_h[0][l0 + 1] * s_h[1][l0 + 1] + s_h[2][l0] * s_h[3][l0] +
+                                      s_h[2][l0 + 1] * s_h[3][l0 + 1]);
+                    } else {
+                        const double w4[4] = {1.0, 5.0, 5.0, 1.0};
+                        const double d = 1.0 / 12.0;
+                        double ysum = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < N; ++jj)
+#pragma unroll
+                            for (int ii = 0; ii < N; ++ii)
+                                ysum = ysum + w4[ii & 3] * w4[jj & 3] * (s_h[2 * jj][l0 + ii] * s_h[2 * jj + 1][l0 + ii]);
+                        da = d * d * ysum;
+                    }
+                    p.out2[row * p.nx + ci] = da * p.Re * p.Re;
+                }
+            }
+            // the next chunk's first writes to s_h happen after two more barriers, which every thread passes only
+            // after it has finished the reads above
+        }
+    }  // chunks
+}
+
+template <int F, int N, int MODE>
+int launch_sweep(const SweepParams& p, long blocks, hipStream_t s) {
+    if (blocks <= 0) return OGG_OK;
+    dpole_sweep_kernel<F, N, MODE><<<(unsigned)blocks, SW_TX, 0, s>>>(p);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
+
+int check_cap(long ni, long nj) {
+    OGG_REQUIRE(ni > 0 && nj > 0, OGG_ESHAPE, "displaced pole cap: ni=%ld nj=%ld", ni, nj);
+    return OGG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ogg_displaced_pole_mesh_dev(long n_i, const double* i, long n_j, const double* j, long ni, long nj, double lon0,
+                                double lat0, double lam_pole, double r_pole, double* lams, double* phis, void* stream) {
+    if (int e = check_cap(ni, nj)) return e;
+    OGG_REQUIRE(n_i > 0 && n_j >= 0 && i && j && lams && phis, OGG_EARG, "ogg_displaced_pole_mesh: bad argument");
+    SweepParams p{};
+    p.ni = ni, p.nj = nj, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lam_pole, p.r_pole = r_pole;
+    p.eps = 1.0, p.Re = 1.0;
+    p.n_cols = n_i, p.n_rows = n_j, p.i_arr = i, p.j_arr = j;
+    p.out0 = lams, p.out1 = phis;
+    return launch_sweep<0, 1, MODE_MESH>(p, n_j, ogg::as_stream(stream));
+}
+
+int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0, long nrows,
+                                double* x, double* y, void* stream) {
+    if (int e = check_cap(Ni, Nj)) return e;
+    OGG_REQUIRE(j0 >= 0 && nrows >= 0 && j0 + nrows <= Nj + 1 && x && y, OGG_ESHAPE,
+                "ogg_displaced_pole_grid: rows %ld..%ld outside 0..%ld", j0, j0 + nrows, Nj);
+    SweepParams p{};
+    p.ni = Ni, p.nj = Nj, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
+    p.eps = 1.0, p.Re = 1.0;
+    p.n_cols = Ni + 1, p.n_rows = nrows, p.i_arr = nullptr, p.j_arr = nullptr, p.j0 = j0;
+    p.out0 = x, p.out1 = y;
+    return launch_sweep<0, 1, MODE_MESH>(p, nrows, ogg::as_stream(stream));
+}
+
+int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, const double* j, long nx, long ny, double lon0,
+                                       double lat0, double lon_dp, double r_dp, double eps, int fd_order, double* h_i,
+                                       double* h_j, void* stream) {
+    if (int e = check_cap(nx, ny)) return e;
+    OGG_REQUIRE(fd_order == 2 || fd_order == 4 || fd_order == 6, OGG_EORDER, "order not coded");
+    OGG_REQUIRE(n_i > 0 && n_j >= 0 && i && j && (h_i || h_j) && eps > 0, OGG_EARG, "ogg_displaced_pole_numerical_h: bad argument");
+    SweepParams p{};
+    p.ni = nx, p.nj = ny, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
+    p.eps = eps, p.Re = 1.0;
+    p.n_cols = n_i, p.n_rows = n_j, p.i_arr = i, p.j_arr = j;
+    p.out0 = h_i, p.out1 = h_j;
+    hipStream_t s = ogg::as_stream(stream);
+    if (fd_order == 2) return launch_sweep<2, 1, MODE_EMIT>(p, n_j, s);
+    if (fd_order == 4) return launch_sweep<4, 1, MODE_EMIT>(p, n_j, s);
+    return launch_sweep<6, 1, MODE_EMIT>(p, n_j, s);
+}
+
+int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                        double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
+                                        double* daq, void* stream) {
+    OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
+    // the quadrature order is forwarded as the finite-difference order (OGG:583-584): 3 and 5 are "not coded" there
+    OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
+    if (int e = check_cap(nx, ny)) return e;
+    OGG_REQUIRE(dxq && dyq && daq, OGG_EARG, "ogg_displaced_pole_metrics_quad: null output");
+    OGG_REQUIRE(j0 >= 0 && n_cell_rows >= 0 && j0 + n_cell_rows <= ny &&
+                    (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
+                OGG_ESHAPE, "ogg_displaced_pole_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0,
+                n_cell_rows, n_dx_rows, ny);
+    SweepParams p{};
+    p.ni = nx, p.nj = ny, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
+    p.eps = 1e-3, p.Re = Re;  // OGG:583
+    p.nx = nx, p.ny = ny, p.j0 = j0;
+    p.n_cols = (long)(order - 1) * nx + 1;
+    p.n_rows = n_cell_rows;
+    p.q = ogg::quad_nodes_host(order);
+    p.out0 = dxq, p.out1 = dyq, p.out2 = daq;
+    hipStream_t s = ogg::as_stream(stream);
+    int e;
+    p.top_row = 0;
+    e = (order == 2) ? launch_sweep<2, 2, MODE_QUAD>(p, n_cell_rows, s) : launch_sweep<4, 4, MODE_QUAD>(p, n_cell_rows, s);
+    if (e) return e;
+    if (n_dx_rows > n_cell_rows) {
+        p.top_row = 1;
+        p.out_row = n_cell_rows;
+        e = (order == 2) ? launch_sweep<2, 2, MODE_QUAD>(p, 1, s) : launch_sweep<4, 4, MODE_QUAD>(p, 1, s);
+    }
+    return e;
+}
+
+}  // extern "C"

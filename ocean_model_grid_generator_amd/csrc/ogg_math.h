@@ -1,0 +1,82 @@
+// Device-side scalar helpers shared by all kernels.  gfx950 only.
+//
+// Arithmetic contract: every kernel in this library is compiled with -ffp-contract=off and follows the operation
+// order of the reference script (ocean_grid_generator.py, "OGG:<line>" below) so that the only differences
+// from a CPU evaluation of the same formulas are the last-ulp differences of the transcendental functions
+// (ocml on the device).  Where numpy itself fuses (its complex multiply is fma(ar,br,-(ai*bi)), its complex
+// absolute is a*sqrt(fma(r,r,1))), the explicit fma() is written out here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define OGG_DEV __device__ __forceinline__
+
+namespace ogg {
+
+constexpr double kPi = 3.141592653589793;        // numpy.pi
+constexpr double kPi180 = kPi / 180.0;            // OGG:13  PI_180
+constexpr double k180Pi = 180.0 / kPi;            // OGG:301 (180/np.pi), also np.angle(deg=True)
+constexpr double kHuge = 1.0e30;                  // OGG:16
+constexpr double kReDefault = 6371.0e3;           // OGG:15
+
+// numpy.mod(a, 360.0): result carries the sign of the divisor.
+OGG_DEV double pymod360(double a) {
+    double r = fmod(a, 360.0);
+    if (r < 0.0) r += 360.0;
+    return (r == 0.0) ? 0.0 : r;
+}
+
+// OGG:682-684 mdist: positive distance modulo 360.
+OGG_DEV double mdist(double x1, double x2) {
+    return fmin(pymod360(x1 - x2), pymod360(x2 - x1));
+}
+
+struct cplx {
+    double re, im;
+};
+
+// numpy complex128 multiply as the SIMD loop evaluates it (checked bit-for-bit on the build host).
+OGG_DEV cplx cmul(cplx a, cplx b) {
+    cplx o;
+    o.re = fma(a.re, b.re, -(a.im * b.im));
+    o.im = fma(a.re, b.im, a.im * b.re);
+    return o;
+}
+
+// numpy complex128 divide: Smith's algorithm, no fma.
+OGG_DEV cplx cdiv(cplx a, cplx b) {
+    cplx o;
+    if (fabs(b.re) >= fabs(b.im)) {
+        const double rat = b.im / b.re;
+        const double scl = 1.0 / (b.re + b.im * rat);
+        o.re = (a.re + a.im * rat) * scl;
+        o.im = (a.im - a.re * rat) * scl;
+    } else {
+        const double rat = b.re / b.im;
+        const double scl = 1.0 / (b.im + b.re * rat);
+        o.re = (a.re * rat + a.im) * scl;
+        o.im = (a.im * rat - a.re) * scl;
+    }
+    return o;
+}
+
+// numpy.absolute(complex128): max * sqrt(1 + (min/max)^2) with one fma.
+OGG_DEV double cabs_np(cplx w) {
+    const double ar = fabs(w.re), ai = fabs(w.im);
+    const double a = fmax(ar, ai), b = fmin(ar, ai);
+    if (a == 0.0) return 0.0;
+    const double r = b / a;
+    return a * sqrt(fma(r, r, 1.0));
+}
+
+// Gauss-Lobatto node weights of OGG:191-204, computed on the host in IEEE double and passed by value.
+struct QuadNodes {
+    double a[5];
+    double b[5];
+};
+
+// OGG:145 / OGG:155: node k of cell c  ->  b[k]*c + a[k]*(c+1)
+OGG_DEV double lattice_node(const QuadNodes& q, int k, long c) {
+    return q.b[k] * (double)c + q.a[k] * (double)(c + 1);
+}
+
+}  // namespace ogg
