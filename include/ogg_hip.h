@@ -43,6 +43,10 @@ int ogg_device_name(char* buf, int buflen);
 int ogg_y_mercator_rounded(long Ni, long n, const double* phi_rad, long long* ystar);
 int ogg_y_mercator_rounded_dev(long Ni, long n, const double* phi_rad, long long* ystar, void* stream);
 
+/* y_mercator (OGG:292-295): the unrounded ordinate y = R*log((1+sin(phi))/cos(phi)) */
+int ogg_y_mercator(long Ni, long n, const double* phi_rad, double* y);
+int ogg_y_mercator_dev(long Ni, long n, const double* phi_rad, double* y, void* stream);
+
 /* phi_mercator (OGG:298-301): phi = atan(sinh(y/R))*(180/pi), degrees, for arbitrary ordinates y[n]. */
 int ogg_phi_mercator(long Ni, long n, const double* y, double* phi_deg);
 int ogg_phi_mercator_dev(long Ni, long n, const double* y, double* phi_deg, void* stream);
@@ -51,6 +55,10 @@ int ogg_mercator_axis_dev(long Ni, long long y0, long n, double* phi_deg, void* 
 
 /* out[k] = a0 + (k*len)/denom, k = 0..n-1: the axes of OGG:113,115,431,834,835 */
 int ogg_linear_axis_dev(long n, double a0, double len, double denom, double* out, void* stream);
+
+/* out[k] = a0 + (idx[k]*len)/denom for arbitrary (fractional) indices idx[n]: OGG:126-127, 479-482 */
+int ogg_affine_index(long n, const double* idx, double a0, double len, double denom, double* out);
+int ogg_affine_index_dev(long n, const double* idx, double a0, double len, double denom, double* out, void* stream);
 
 /* np.tile pair (OGG:430-432, OGG:840-841): x[j][i] = lon1d[i], y[j][i] = lat1d[j]; rows j0..j0+nrows-1 of the
  * lat axis are written to nrows x ni1 outputs. */
@@ -66,6 +74,10 @@ int ogg_generate_latlon_grid(long lni, long lnj, double llon0, double llen_lon, 
 /* ------------------------------------------------------------------------------------------------------
  * MIDAS stencil metrics (OGG:687-716) and grid orientation angle (OGG:719-729), fused
  * ---------------------------------------------------------------------------------------------------- */
+
+/* mdist (OGG:682-684): min(mod(x1-x2,360), mod(x2-x1,360)) with numpy's sign-of-divisor mod, element-wise */
+int ogg_mdist(long n, const double* x1, const double* x2, double* out);
+int ogg_mdist_dev(long n, const double* x1, const double* x2, double* out, void* stream);
 
 /* x, y: nrows_xy x ni1 point rows.  Writes
  *   dx    [n_pt_rows  ][ni1-1]   (rows 0..n_pt_rows-1)            if dx    != NULL
@@ -102,6 +114,13 @@ int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, lo
 int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis,
                          double* h_i_inv, double* h_j_inv);
 
+/* bipolar_cap_ij_array (OGG:125-133): per-index arc lengths (radians) at fractional indices i[n_i], j[n_j];
+ * h_i_inv, h_j_inv: n_j x n_i */
+int ogg_bipolar_cap_ij_array(long n_i, const double* i, long n_j, const double* j, long Ni, long Nj, double lat0_bp,
+                             double lon_bp, double rp, double* h_i_inv, double* h_j_inv);
+int ogg_bipolar_cap_ij_array_dev(long n_i, const double* i, long n_j, const double* j, long Ni, long Nj, double lat0_bp,
+                                 double lon_bp, double rp, double* h_i_inv, double* h_j_inv, void* stream);
+
 /* bipolar_cap_metrics_quad_fast (OGG:136-188): Gauss-Lobatto quadrature (order 2..5) of the analytic scale
  * factors.  Band form: dxq rows j0..j0+n_dx_rows-1 of (ny+1) x nx; dyq rows j0..j0+n_cell_rows-1 of ny x (nx+1);
  * daq rows j0..j0+n_cell_rows-1 of ny x nx. */
@@ -122,6 +141,20 @@ int ogg_displaced_pole_mesh_dev(long n_i, const double* i, long n_j, const doubl
                                 void* stream);
 int ogg_displaced_pole_mesh(long n_i, const double* i, long n_j, const double* j, long ni, long nj, double lon0,
                             double lat0, double lam_pole, double r_pole, double* lams, double* phis);
+/* displacedPoleCap_projection (OGG:447-467) on explicit lon/lat grids (nj x ni) with z_0 = z0_re + i z0_im and
+ * r_joint given; x_0 is the seed of the unwrap (the reference passes lon_grid[0,0], OGG:463). */
+int ogg_displaced_pole_projection(long nj, long ni, const double* lon_grid, const double* lat_grid, double z0_re,
+                                  double z0_im, double r_joint, double x_0, double* lam, double* phi);
+int ogg_displaced_pole_projection_dev(long nj, long ni, const double* lon_grid, const double* lat_grid, double z0_re,
+                                      double z0_im, double r_joint, double x_0, double* lam, double* phi, void* stream);
+/* monotonic_bounding (OGG:470-475), in place on x (nj x ni) */
+int ogg_monotonic_bounding(long nj, long ni, double* x, double x_0);
+int ogg_monotonic_bounding_dev(long nj, long ni, double* x, double x_0, void* stream);
+/* the haversine of great_arc_distance (OGG:527-532), element-wise; inputs in degrees, output in radians */
+int ogg_haversine(long n, const double* lam0, const double* phi0, const double* lam1, const double* phi1, double* out);
+int ogg_haversine_dev(long n, const double* lam0, const double* phi0, const double* lam1, const double* phi1, double* out,
+                      void* stream);
+
 /* generate_displaced_pole_grid (OGG:509-518), rows j0..j0+nrows-1 of (Nj+1) x (Ni+1). */
 int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0,
                                 long nrows, double* x, double* y, void* stream);

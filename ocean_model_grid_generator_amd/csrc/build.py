@@ -1,0 +1,67 @@
+"""Build libogg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m ocean_model_grid_generator_amd.csrc.build [--force] [--verbose]
+
+-ffp-contract=off is part of the arithmetic contract (see ogg_math.h): products and sums are rounded separately
+exactly as numpy rounds them; the only fused operations are the explicit fma() calls.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["ogg_api.hip", "ogg_axes.hip", "ogg_midas.hip", "ogg_bipolar.hip", "ogg_dpole.hip", "ogg_elementwise.hip", "ogg_pipeline.hip"]
+HEADERS = ["ogg_common.h", "ogg_math.h", "../../include/ogg_hip.h"]
+LIB = os.path.join(HERE, "libogg_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+         "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS if os.path.exists(os.path.join(HERE, f))] + [__file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        path = os.path.join(HERE, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        cmd = [cc] + FLAGS + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
+        if verbose and out.strip():
+            print(out)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stdout)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

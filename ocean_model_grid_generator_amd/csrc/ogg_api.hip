@@ -301,4 +301,86 @@ int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, do
     return download(daq, d_da, ny * nx);
 }
 
+// ---- small element-wise entry points -----------------------------------------------------------------------
+int ogg_y_mercator(long Ni, long n, const double* phi_rad, double* y) {
+    OGG_REQUIRE(n >= 0 && phi_rad && y, OGG_EARG, "ogg_y_mercator: bad argument");
+    DevScratch s;
+    double *d_in, *d_out;
+    OGG_TRY(s.upload(&d_in, phi_rad, n));
+    OGG_TRY(s.alloc(&d_out, n));
+    OGG_TRY(ogg_y_mercator_dev(Ni, n, d_in, d_out, nullptr));
+    return download(y, d_out, n);
+}
+
+int ogg_affine_index(long n, const double* idx, double a0, double len, double denom, double* out) {
+    OGG_REQUIRE(n >= 0 && idx && out, OGG_EARG, "ogg_affine_index: bad argument");
+    DevScratch s;
+    double *d_in, *d_out;
+    OGG_TRY(s.upload(&d_in, idx, n));
+    OGG_TRY(s.alloc(&d_out, n));
+    OGG_TRY(ogg_affine_index_dev(n, d_in, a0, len, denom, d_out, nullptr));
+    return download(out, d_out, n);
+}
+
+int ogg_mdist(long n, const double* x1, const double* x2, double* out) {
+    OGG_REQUIRE(n >= 0 && x1 && x2 && out, OGG_EARG, "ogg_mdist: bad argument");
+    DevScratch s;
+    double *d_a, *d_b, *d_out;
+    OGG_TRY(s.upload(&d_a, x1, n));
+    OGG_TRY(s.upload(&d_b, x2, n));
+    OGG_TRY(s.alloc(&d_out, n));
+    OGG_TRY(ogg_mdist_dev(n, d_a, d_b, d_out, nullptr));
+    return download(out, d_out, n);
+}
+
+int ogg_haversine(long n, const double* lam0, const double* phi0, const double* lam1, const double* phi1, double* out) {
+    OGG_REQUIRE(n >= 0 && lam0 && phi0 && lam1 && phi1 && out, OGG_EARG, "ogg_haversine: bad argument");
+    DevScratch s;
+    double *d0, *d1, *d2, *d3, *d_out;
+    OGG_TRY(s.upload(&d0, lam0, n));
+    OGG_TRY(s.upload(&d1, phi0, n));
+    OGG_TRY(s.upload(&d2, lam1, n));
+    OGG_TRY(s.upload(&d3, phi1, n));
+    OGG_TRY(s.alloc(&d_out, n));
+    OGG_TRY(ogg_haversine_dev(n, d0, d1, d2, d3, d_out, nullptr));
+    return download(out, d_out, n);
+}
+
+int ogg_bipolar_cap_ij_array(long n_i, const double* i, long n_j, const double* j, long Ni, long Nj, double lat0_bp,
+                             double lon_bp, double rp, double* h_i_inv, double* h_j_inv) {
+    OGG_REQUIRE(n_i > 0 && n_j >= 0 && i && j && h_i_inv && h_j_inv, OGG_EARG, "ogg_bipolar_cap_ij_array: bad argument");
+    DevScratch s;
+    double *d_i, *d_j, *d_hi, *d_hj;
+    OGG_TRY(s.upload(&d_i, i, n_i));
+    OGG_TRY(s.upload(&d_j, j, n_j));
+    OGG_TRY(s.alloc(&d_hi, n_i * n_j));
+    OGG_TRY(s.alloc(&d_hj, n_i * n_j));
+    OGG_TRY(ogg_bipolar_cap_ij_array_dev(n_i, d_i, n_j, d_j, Ni, Nj, lat0_bp, lon_bp, rp, d_hi, d_hj, nullptr));
+    OGG_TRY(download(h_i_inv, d_hi, n_i * n_j));
+    return download(h_j_inv, d_hj, n_i * n_j);
+}
+
+int ogg_displaced_pole_projection(long nj, long ni, const double* lon_grid, const double* lat_grid, double z0_re, double z0_im,
+                                  double r_joint, double x_0, double* lam, double* phi) {
+    OGG_REQUIRE(nj >= 0 && ni > 0 && lon_grid && lat_grid && lam && phi, OGG_EARG, "ogg_displaced_pole_projection: bad argument");
+    DevScratch s;
+    double *d_lon, *d_lat, *d_l, *d_p;
+    OGG_TRY(s.upload(&d_lon, lon_grid, nj * ni));
+    OGG_TRY(s.upload(&d_lat, lat_grid, nj * ni));
+    OGG_TRY(s.alloc(&d_l, nj * ni));
+    OGG_TRY(s.alloc(&d_p, nj * ni));
+    OGG_TRY(ogg_displaced_pole_projection_dev(nj, ni, d_lon, d_lat, z0_re, z0_im, r_joint, x_0, d_l, d_p, nullptr));
+    OGG_TRY(download(lam, d_l, nj * ni));
+    return download(phi, d_p, nj * ni);
+}
+
+int ogg_monotonic_bounding(long nj, long ni, double* x, double x_0) {
+    OGG_REQUIRE(nj >= 0 && ni > 0 && x, OGG_EARG, "ogg_monotonic_bounding: bad argument");
+    DevScratch s;
+    double* d_x;
+    OGG_TRY(s.upload(&d_x, x, nj * ni));
+    OGG_TRY(ogg_monotonic_bounding_dev(nj, ni, d_x, x_0, nullptr));
+    return download(x, d_x, nj * ni);
+}
+
 }  // extern "C"

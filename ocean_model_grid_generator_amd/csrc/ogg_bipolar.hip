@@ -272,6 +272,24 @@ __global__ __launch_bounds__(QT_THREADS) void bipolar_quad_kernel(QuadParams p) 
     p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;                                       // OGG:185
 }
 
+
+// ---- bipolar_cap_ij_array (OGG:125-133) at arbitrary fractional indices ---------------------------------------
+__global__ void bipolar_ij_kernel(long n_i, const double* __restrict__ iv, long n_j, const double* __restrict__ jv, long Ni,
+                                  long Nj, double lat0_bp, double lon_bp, double rp, double* __restrict__ hi,
+                                  double* __restrict__ hj) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r = blockIdx.y;
+    if (k >= n_i || r >= n_j) return;
+    const double lon = lon_bp + (iv[k] * 360.0) / (double)Ni;
+    const double lat = lat0_bp + (jv[r] * (90 - lat0_bp)) / (double)Nj;
+    const BpRow row = bp_row(lat, rp);
+    const BpCol col = bp_col(lon, lon_bp);
+    double phis, h_i, h_j, rden;
+    bp_point(row, col, rp, phis, h_i, h_j, rden);
+    hi[r * n_i + k] = h_i * 2 * kPi / (double)Ni;
+    hj[r * n_i + k] = h_j * (90 - lat0_bp) * kPi180 / (double)Nj;
+}
+
 QuadNodes make_nodes(int order) {  // OGG:191-204, host IEEE double
     QuadNodes q{};
     if (order == 2) {
@@ -342,11 +360,22 @@ int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, lo
     return OGG_OK;
 }
 
+int ogg_bipolar_cap_ij_array_dev(long n_i, const double* i, long n_j, const double* j, long Ni, long Nj, double lat0_bp,
+                                 double lon_bp, double rp, double* h_i_inv, double* h_j_inv, void* stream) {
+    OGG_REQUIRE(n_i > 0 && n_j >= 0 && i && j && h_i_inv && h_j_inv && Ni > 0 && Nj > 0, OGG_EARG,
+                "ogg_bipolar_cap_ij_array: bad argument");
+    if (n_j == 0) return OGG_OK;
+    dim3 grid((unsigned)((n_i + 255) / 256), (unsigned)n_j);
+    bipolar_ij_kernel<<<grid, 256, 0, ogg::as_stream(stream)>>>(n_i, i, n_j, j, Ni, Nj, lat0_bp, lon_bp, rp, h_i_inv, h_j_inv);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
+
 int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
                                      long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
                                      void* stream) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
-    OGG_REQUIRE(nx > 0 && ny > 0 && dxq && dyq && daq, OGG_EARG, "ogg_bipolar_cap_metrics_quad: bad argument");
+    OGG_REQUIRE(nx > 0 && ny > 0 && dxq && (n_cell_rows <= 0 || (dyq && daq)), OGG_EARG, "ogg_bipolar_cap_metrics_quad: bad argument");
     OGG_REQUIRE(j0 >= 0 && n_cell_rows >= 0 && j0 + n_cell_rows <= ny &&
                     (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
                 OGG_ESHAPE, "ogg_bipolar_cap_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0, n_cell_rows,

@@ -111,6 +111,75 @@ OGG_DEV double great_arc(double lam0d, double phi0d, double lam1d, double phi1d)
     return 2.0 * asin(sqrt(d));
 }
 
+
+// ---- monotonic_bounding (OGG:470-475) as a workgroup-wide scan of 1-bit maps ------------------------------------
+template <int NP>
+struct UnwrapShared {
+    double v[NP][SW_TX];
+    unsigned w0[SW_WAVES], w1[SW_WAVES];
+};
+
+// Packed "was lowered by 360" states of this thread's column for NP independent scans.  v: raw values of this
+// column; first_col: this is column 0 of the row (compared with seed[], no dependence on a previous state);
+// carry_v / carry_state_ptr: raw values and states of the column just before this chunk (LDS; the caller rewrites
+// them only AFTER this function returns).  Contains two workgroup barriers: every thread of the workgroup must call it
+// (inactive threads contribute the identity map).
+template <int NP>
+OGG_DEV unsigned unwrap_states(const double* v, bool active, bool first_col, const double* seed, const double* carry_v,
+                               const unsigned* carry_state_ptr, UnwrapShared<NP>& sh) {
+    constexpr unsigned ALL = (NP >= 32) ? 0xffffffffu : ((1u << NP) - 1u);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) sh.v[q][tid] = v[q];
+    __syncthreads();
+    // The carry of the previous chunk was written after that chunk's second barrier; this read sits behind the
+    // barrier above, and the next write sits behind the barrier below: no race in either direction.
+    const unsigned carry_state = *carry_state_ptr;
+    double cv[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) cv[q] = carry_v[q];
+    unsigned f0 = 0u, f1 = ALL;  // identity map
+    if (active) {
+        f0 = 0u;
+        f1 = 0u;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            bool b0, b1;
+            if (first_col) {
+                b0 = b1 = (v[q] - seed[q] > 100);
+            } else {
+                const double vp = (tid > 0) ? sh.v[q][tid - 1] : cv[q];
+                b0 = (v[q] - vp > 100);          // previous column was not lowered
+                b1 = (v[q] - (vp - 360) > 100);  // previous column was lowered (x_im1 = vp - 360, OGG:473-474)
+            }
+            f0 |= (b0 ? 1u : 0u) << q;
+            f1 |= (b1 ? 1u : 0u) << q;
+        }
+    }
+    // inclusive wave64 scan of the composition (later o earlier)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned e0 = __shfl_up(f0, off);
+        const unsigned e1 = __shfl_up(f1, off);
+        if (lane >= off) {
+            const unsigned h0 = (e0 & f1) | (~e0 & f0);
+            const unsigned h1 = (e1 & f1) | (~e1 & f0);
+            f0 = h0;
+            f1 = h1;
+        }
+    }
+    if (lane == 63) {
+        sh.w0[wave] = f0;
+        sh.w1[wave] = f1;
+    }
+    __syncthreads();
+    unsigned st = carry_state;
+    for (int w = 0; w < wave; ++w) st = (st & sh.w1[w]) | (~st & sh.w0[w]);
+    return ((st & f1) | (~st & f0)) & ALL;
+}
+
 template <int F>
 OGG_DEV double central_difference(const double* ds, double reps) {  // OGG:539-546
     if (F == 2) return 0.5 * ds[0] * reps;
@@ -135,20 +204,16 @@ __global__ __launch_bounds__(SW_TX) void dpole_sweep_kernel(SweepParams p) {
     constexpr int NP = (MODE == MODE_MESH) ? 1 : 2 * F;  // probes per lattice point: H x {+,-} x {i, j}
     constexpr int NV = (MODE == MODE_MESH) ? 1 : 1 + F;  // distinct column (and row) variants: base, +-m*eps
     constexpr int M = (N > 1) ? N - 1 : 1;          // unique columns per cell (QUAD)
-    constexpr unsigned ALL = (NP >= 32) ? 0xffffffffu : ((1u << NP) - 1u);
     constexpr int STEP = (MODE == MODE_QUAD) ? (255 / M) * M : SW_TX;  // new columns per chunk
     constexpr int CELLS = STEP / M;                 // QUAD: cells per chunk
 
-    __shared__ double s_v[NP][SW_TX];
+    __shared__ UnwrapShared<NP> s_u;
     __shared__ double s_carry_v[N][NP];
     __shared__ unsigned s_carry_state[N];
-    __shared__ unsigned s_w0[SW_WAVES], s_w1[SW_WAVES];
     __shared__ double s_r[N][NV];
     __shared__ double s_h[(MODE == MODE_QUAD) ? 2 * N : 1][SW_TX];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     const DpConst c = dp_const(p);
     const double reps = 1.0 / p.eps;
     const long row = blockIdx.x;  // lattice row (MESH/EMIT) or band-local cell row (QUAD)
@@ -223,57 +288,18 @@ __global__ __launch_bounds__(SW_TX) void dpole_sweep_kernel(SweepParams p) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) v[q] = 0.0, ph[q] = 0.0;
             }
+            double seed[NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) s_v[q][tid] = v[q];
-            const unsigned carry_state = s_carry_state[kk];  // read before anybody rewrites it below
-            __syncthreads();
-
-            // 1-bit maps f(0), f(1) of every probe, packed
-            unsigned f0 = 0u, f1 = ALL;  // identity
-            if (active) {
-                f0 = 0u;
-                f1 = 0u;
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    bool b0, b1;
-                    if (g == 0) {
-                        // first column: compared with the seed, independent of any state
-                        double di = 0.0;
-                        if (MODE != MODE_MESH && q < F) {
-                            const double off = (double)(q / 2 + 1) * p.eps;
-                            di = (q & 1) ? -off : off;
-                        }
-                        const double seed = p.lon0 + ((i_first + di) * 360.0) / (double)p.ni;
-                        b0 = b1 = (v[q] - seed > 100);
-                    } else {
-                        const double vp = (tid > 0) ? s_v[q][tid - 1] : s_carry_v[kk][q];
-                        b0 = (v[q] - vp > 100);
-                        b1 = (v[q] - (vp - 360) > 100);
-                    }
-                    f0 |= (b0 ? 1u : 0u) << q;
-                    f1 |= (b1 ? 1u : 0u) << q;
+            for (int q = 0; q < NP; ++q) {
+                // first column: compared with the seed lon_grid[0,0] (OGG:463), independent of any state
+                double di = 0.0;
+                if (MODE != MODE_MESH && q < F) {
+                    const double off = (double)(q / 2 + 1) * p.eps;
+                    di = (q & 1) ? -off : off;
                 }
+                seed[q] = p.lon0 + ((i_first + di) * 360.0) / (double)p.ni;
             }
-            // inclusive wave scan of the composition (later o earlier)
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned e0 = __shfl_up(f0, off);
-                const unsigned e1 = __shfl_up(f1, off);
-                if (lane >= off) {
-                    const unsigned h0 = (e0 & f1) | (~e0 & f0);
-                    const unsigned h1 = (e1 & f1) | (~e1 & f0);
-                    f0 = h0;
-                    f1 = h1;
-                }
-            }
-            if (lane == 63) {
-                s_w0[wave] = f0;
-                s_w1[wave] = f1;
-            }
-            __syncthreads();
-            unsigned st = carry_state;
-            for (int w = 0; w < wave; ++w) st = (st & s_w1[w]) | (~st & s_w0[w]);
-            st = ((st & f1) | (~st & f0)) & ALL;  // state of this column, all probes
+            const unsigned st = unwrap_states<NP>(v, active, g == 0, seed, s_carry_v[kk], &s_carry_state[kk], s_u);
 
             if (active && tid == carry_tid) {
 #pragma unroll
@@ -359,6 +385,57 @@ __global__ __launch_bounds__(SW_TX) void dpole_sweep_kernel(SweepParams p) {
     }  // chunks
 }
 
+
+// ---- displacedPoleCap_projection on explicit 2-D lon/lat grids (OGG:447-467) and bare monotonic_bounding ---------
+struct DirectParams {
+    long nj, ni;
+    const double* lon;  // PROJECT: lon_grid; UNWRAP: unused
+    const double* lat;
+    double z0r, z0i, r_joint, x0;
+    double* lam;        // PROJECT: out; UNWRAP: in/out
+    double* phi;
+};
+
+template <bool PROJECT>
+__global__ __launch_bounds__(SW_TX) void dpole_direct_kernel(DirectParams p) {
+    __shared__ UnwrapShared<1> s_u;
+    __shared__ double s_carry_v[1];
+    __shared__ unsigned s_carry_state;
+    const int tid = threadIdx.x;
+    const long row = blockIdx.x;
+    const DpConst c = {p.z0r, p.z0i, p.r_joint};
+    for (long c0 = 0; c0 < p.ni; c0 += SW_TX) {
+        const long g = c0 + tid;
+        const bool active = g < p.ni;
+        double v[1] = {0.0}, ph = 0.0;
+        if (active) {
+            if (PROJECT) {
+                const double lon = p.lon[row * p.ni + g], lat = p.lat[row * p.ni + g];
+                const double r = tan((90 + lat) * kPi180) / p.r_joint;  // OGG:448
+                double s, co;
+                sincos(lon * kPi180, &s, &co);
+                const cplx e = {co, s};
+                const cplx num = {e.re - c.z0r, e.im - c.z0i};
+                const cplx cz = cmul(cplx{c.z0r, -c.z0i}, e);
+                const cplx den = {1.0 - cz.re, 0.0 - cz.im};
+                dp_point(r, cdiv(num, den), c, v[0], ph);
+            } else {
+                v[0] = p.lam[row * p.ni + g];
+            }
+        }
+        const double seed[1] = {p.x0};
+        const unsigned st = unwrap_states<1>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
+        if (active && tid == SW_TX - 1) {
+            s_carry_v[0] = v[0];
+            s_carry_state = st;
+        }
+        if (active) {
+            p.lam[row * p.ni + g] = (st & 1u) ? v[0] - 360 : v[0];
+            if (PROJECT) p.phi[row * p.ni + g] = ph;
+        }
+    }
+}
+
 template <int F, int N, int MODE>
 int launch_sweep(const SweepParams& p, long blocks, hipStream_t s) {
     if (blocks <= 0) return OGG_OK;
@@ -386,6 +463,25 @@ int ogg_displaced_pole_mesh_dev(long n_i, const double* i, long n_j, const doubl
     p.n_cols = n_i, p.n_rows = n_j, p.i_arr = i, p.j_arr = j;
     p.out0 = lams, p.out1 = phis;
     return launch_sweep<0, 1, MODE_MESH>(p, n_j, ogg::as_stream(stream));
+}
+
+int ogg_displaced_pole_projection_dev(long nj, long ni, const double* lon_grid, const double* lat_grid, double z0_re,
+                                      double z0_im, double r_joint, double x_0, double* lam, double* phi, void* stream) {
+    OGG_REQUIRE(nj >= 0 && ni > 0 && lon_grid && lat_grid && lam && phi, OGG_EARG, "ogg_displaced_pole_projection: bad argument");
+    if (nj == 0) return OGG_OK;
+    DirectParams p{nj, ni, lon_grid, lat_grid, z0_re, z0_im, r_joint, x_0, lam, phi};
+    dpole_direct_kernel<true><<<(unsigned)nj, SW_TX, 0, ogg::as_stream(stream)>>>(p);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
+
+int ogg_monotonic_bounding_dev(long nj, long ni, double* x, double x_0, void* stream) {
+    OGG_REQUIRE(nj >= 0 && ni > 0 && x, OGG_EARG, "ogg_monotonic_bounding: bad argument");
+    if (nj == 0) return OGG_OK;
+    DirectParams p{nj, ni, nullptr, nullptr, 0.0, 0.0, 1.0, x_0, x, nullptr};
+    dpole_direct_kernel<false><<<(unsigned)nj, SW_TX, 0, ogg::as_stream(stream)>>>(p);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
 }
 
 int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0, long nrows,
@@ -425,7 +521,7 @@ int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0
     // the quadrature order is forwarded as the finite-difference order (OGG:583-584): 3 and 5 are "not coded" there
     OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
     if (int e = check_cap(nx, ny)) return e;
-    OGG_REQUIRE(dxq && dyq && daq, OGG_EARG, "ogg_displaced_pole_metrics_quad: null output");
+    OGG_REQUIRE(dxq && (n_cell_rows <= 0 || (dyq && daq)), OGG_EARG, "ogg_displaced_pole_metrics_quad: null output");
     OGG_REQUIRE(j0 >= 0 && n_cell_rows >= 0 && j0 + n_cell_rows <= ny &&
                     (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
                 OGG_ESHAPE, "ogg_displaced_pole_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0,

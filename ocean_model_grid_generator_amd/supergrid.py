@@ -1,0 +1,327 @@
+"""Device-resident, latitude-band-sharded supergrid pass (the benchmark / multi-GPU path).
+
+One process per GPU.  Every rank owns a contiguous band of rows of EACH sub-grid (southern cap, Southern Ocean,
+Mercator, bipolar cap): cost per row differs by ~100x between the lat-lon sub-grids and the caps, so cutting the
+stitched grid into contiguous slabs would not balance.  One pass =
+
+  phase A  coordinates   1-D axes (every rank, a few thousand values), lat-lon tiles, bipolar mesh,
+                         displaced-pole mesh                                                   [K1, K3, K5]
+  halo                   the first x/y row of the band above -> the extra row of this band, for the sub-grids whose
+                         metrics use the (j, j+1) stencil; neighbour send/recv over RCCL (torch.distributed "nccl")
+  phase B  metrics       fused MIDAS dx/dy/area + angle_dx; bipolar and displaced-pole quadratures; angle_dx of the
+                         caps                                                                  [K2, K4, K6]
+
+The caps need no exchange (their metrics are analytic in (i, j); the displaced-pole unwrap runs along i inside a
+row).  All six fields of every band stay in HBM (torch tensors); `gather()` copies them out and stitches on the host
+exactly as the reference does (OGG:1315-1365).
+
+torch is used for device memory, streams and torch.distributed only; every number is produced by libogg_hip.so.
+"""
+import math
+
+import numpy as np
+
+from . import _lib as L
+from . import ocean_grid_generator as ogg
+
+FIELDS = ("x", "y", "dx", "dy", "area", "angle_dx")
+
+
+def band(n_rows, rank, world):
+    """Rows [lo, hi) of an n_rows-row sub-grid owned by `rank` (contiguous, balanced to within one row)."""
+    return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
+
+
+class SubGridPlan(object):
+    """Size and scalars of one sub-grid; `row0` is the first KEPT point row in the sub-grid's native numbering
+    (e.g. the first row after the displaced-pole doughnut) and `nj1` the number of kept point rows."""
+
+    def __init__(self, name, kind, nj1, row0=0, **scalars):
+        self.name, self.kind, self.nj1, self.row0 = name, kind, int(nj1), int(row0)
+        self.__dict__.update(scalars)
+
+
+class SupergridPlan(object):
+    """Host-side size logic of main() (OGG:969-1197) for the configurations the pipeline supports (no
+    enhanced_equatorial, no match_dy; south cuts are applied at stitch time).  Needs the GPU: y* and the joint
+    latitudes are read back from device-computed values, exactly as main() reads them from phiMerc."""
+
+    def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0,
+                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, Re=ogg._default_Re):
+        refineS, refineR = 2, inverse_resolution
+        self.Re = Re
+        self.skip_metrics = skip_metrics
+        self.south_cutoff_row = south_cutoff_row
+        self.lon0, self.lenlon = -300.0, 360.0
+        self.Ni = Ni = int(refineR * refineS * 360)
+        q = Ni // 4
+        phi_s, phi_n = -66.85954725, 64.05895973
+        if refineR == 2:
+            phi_s, phi_n = -68.0, 65.0
+        # Mercator ordinate range: device y_mercator_rounded + host parity fixes (OGG:318-334)
+        ys = ogg.y_mercator_rounded(Ni, np.array([phi_s * ogg.PI_180, phi_n * ogg.PI_180]))
+        y0, y1 = int(ys[0]), int(ys[1])
+        if y0 % 2 == 0:
+            y0, y1 = y0 - 1, y1 - 1
+        if (y1 - y0 + 1) % 2 == 0 and ensure_nj_even:
+            y1 -= 1
+        phi_M = ogg.phi_mercator(Ni, np.arange(y0, y1 + 1))
+        if np.searchsorted(phi_M, 0.0) == 0:
+            raise Exception("   Ooops: Equator is not in the grid")
+        skipM = 1 if (phi_M.size % 2 == 0 and ensure_nj_even) else 0
+        self.subs = []
+        merc = SubGridPlan("Merc", "mercator", phi_M.size - skipM, row0=skipM, y0=y0, n_axis=phi_M.size)
+        lat0_bp = float(phi_M[-1])
+        latUp_SO = float(phi_M[skipM])
+        # bipolar cap (OGG:1042-1062)
+        Nj_ncap = int(60 * refineR * refineS)
+        if refineR == 2:
+            Nj_ncap = 119 * refineS
+        if Nj_ncap % 2 != 0 and ensure_nj_even:
+            Nj_ncap -= 1
+        bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=lat0_bp, lon_bp=self.lon0,
+                         rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
+        # Southern Ocean (OGG:1080-1103)
+        lat0_SO = -78.0
+        lenlat_SO = latUp_SO - lat0_SO
+        Nj_SO = int(refineR * 55)
+        skipS = 1 if ((Nj_SO + 1) % 2 == 0 and ensure_nj_even) else 0
+        so = SubGridPlan("SO", "latlon", Nj_SO + 1 - skipS, row0=skipS, lnj=Nj_SO, lat0=lat0_SO, lenlat=lenlat_SO)
+        # southern cap (OGG:1122-1197)
+        lat0_SC = lat0_SO + (skipS * lenlat_SO) / float(Nj_SO) if skipS else lat0_SO
+        Nj_scap = int(refineR * 40) * 7 // 4
+        sc = None
+        if not no_south_cap and Nj_scap != 0:
+            if r_dp == 0.0 and lat_dp <= -90.0:
+                Nj_scap = int((lat0_SC + 90.0) / (1.0 / refineR / refineS))
+                skipC = 1 if ((Nj_scap + 1) % 2 == 0 and ensure_nj_even) else 0
+                sc = SubGridPlan("SC", "latlon", Nj_scap + 1 - skipC, row0=skipC, lnj=Nj_scap, lat0=-90.0, lenlat=90 + lat0_SO)
+            else:
+                if lat_dp > -90:
+                    r_dp = float(np.tan((90 + lat_dp) * ogg.PI_180) / np.tan((90 + lat0_SC) * ogg.PI_180))
+                jmint = 0
+                if exfracdp != 0.0:
+                    jmin = np.ceil(exfracdp * Nj_scap)
+                    jmint = int(jmin + np.mod(jmin, 2))
+                if (Nj_scap + 1 - jmint) % 2 == 0 and ensure_nj_even:
+                    jmint += 1
+                sc = SubGridPlan("SC", "dpole", Nj_scap + 1 - jmint, row0=jmint, Nj=Nj_scap, lat0=lat0_SC, lon_dp=lon_dp, r_dp=r_dp)
+        self.subs = [s for s in (sc, so, merc, bp) if s is not None]  # south -> north
+
+    def rows_cut(self):
+        """Rows removed at the south end of the stitched grid by --south_cutoff_row (OGG:1273-1313): jcut = n-1 rows
+        of the southern cap, or -- when that would consume the whole cap -- the cap and jcut - n_SC rows of the
+        Southern Ocean piece (which is one stitched row less, since stitching drops the cap's last row)."""
+        if self.south_cutoff_row <= 0:
+            return 0
+        jcut = self.south_cutoff_row - 1
+        first = self.subs[0]
+        if first.name == "SC" and jcut >= first.nj1:
+            return jcut - 1
+        return jcut
+
+    @property
+    def nyp(self):
+        return sum(s.nj1 - 1 for s in self.subs) + 1 - self.rows_cut()
+
+    @property
+    def cells(self):
+        """cells of the final stitched grid (the unit of BASELINE.json's metric): (nyp-1)*Ni"""
+        return (self.nyp - 1) * self.Ni
+
+
+class Supergrid(object):
+    """Band-sharded device pass.  `halo` is "rccl" (neighbour send/recv through torch.distributed; needs an initialised
+    process group when world > 1), "local" (world virtual ranks inside ONE process: the neighbour's row is copied
+    device-to-device; used to test the band logic on a single GPU) or "recompute" (the halo row of a lat-lon sub-grid is
+    re-tiled from the 1-D axis every rank already holds; bitwise identical)."""
+
+    def __init__(self, plan, rank=0, world=1, device="cuda:0", halo="rccl", peers=None):
+        import torch
+
+        self.torch = torch
+        self.plan, self.rank, self.world, self.halo = plan, rank, world, halo
+        self.device = torch.device(device)
+        self.peers = peers  # halo="local": list of all virtual ranks' Supergrid objects
+        self.buf = {}
+        self.timings = {}
+        ni1 = plan.Ni + 1
+        with torch.cuda.device(self.device):
+            self.lon1d = torch.empty(ni1, dtype=torch.float64, device=self.device)
+            for s in plan.subs:
+                lo, hi = band(s.nj1, rank, world)
+                n = hi - lo
+                n_cell = min(hi, s.nj1 - 1) - lo  # cell rows owned (a cell row j belongs to the owner of point row j)
+                needs_halo = s.kind in ("mercator", "latlon") and n_cell > 0 and hi < s.nj1
+                b = {"lo": lo, "hi": hi, "n": n, "n_cell": max(n_cell, 0), "needs_halo": needs_halo}
+                rows_xy = n + (1 if needs_halo else 0)
+                for f, (r, c) in (("x", (rows_xy, ni1)), ("y", (rows_xy, ni1)), ("dx", (n, ni1 - 1)), ("dy", (b["n_cell"], ni1)),
+                                  ("area", (b["n_cell"], ni1 - 1)), ("angle_dx", (n, ni1))):
+                    b[f] = torch.empty((max(r, 0), c), dtype=torch.float64, device=self.device)
+                if s.kind == "mercator":
+                    b["axis"] = torch.empty(s.n_axis, dtype=torch.float64, device=self.device)
+                elif s.kind == "latlon":
+                    b["axis"] = torch.empty(s.lnj + 1, dtype=torch.float64, device=self.device)
+                self.buf[s.name] = b
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    @staticmethod
+    def _p(t, row=0):
+        return t.data_ptr() + row * t.stride(0) * 8 if t.dim() == 2 else t.data_ptr() + row * 8
+
+    def _timed(self, key, fn):
+        """Run fn() bracketed by events on the launch stream when per-kernel timing is on."""
+        if self._events is None:
+            fn()
+            return
+        e0 = self.torch.cuda.Event(enable_timing=True)
+        e1 = self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self._events.setdefault(key, []).append((e0, e1))
+
+    _events = None
+
+    # -- phases ----------------------------------------------------------------------------------------------
+    def phase_a(self):
+        """Coordinates of this rank's bands."""
+        p, st = self.plan, self._stream()
+        ni1 = p.Ni + 1
+        L.call("ogg_linear_axis_dev", ni1, p.lon0, p.lenlon, float(p.Ni), self.lon1d.data_ptr(), st)
+        for s in p.subs:
+            b = self.buf[s.name]
+            if b["n"] == 0:
+                continue
+            if s.kind in ("mercator", "latlon"):
+                if s.kind == "mercator":
+                    L.call("ogg_mercator_axis_dev", p.Ni, s.y0, s.n_axis, b["axis"].data_ptr(), st)
+                else:
+                    L.call("ogg_linear_axis_dev", s.lnj + 1, s.lat0, s.lenlat, float(s.lnj), b["axis"].data_ptr(), st)
+                rows = b["n"] + (1 if (b["needs_halo"] and self.halo == "recompute") else 0)
+                self._timed("tile_latlon", lambda: L.call("ogg_tile_latlon_dev", rows, ni1, self._p(b["axis"], s.row0 + b["lo"]),
+                                                          self.lon1d.data_ptr(), b["x"].data_ptr(), b["y"].data_ptr(), st))
+            elif s.kind == "bipolar":
+                self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
+                                                           b["x"].data_ptr(), b["y"].data_ptr(), None, None, st))
+            elif s.kind == "dpole":
+                self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
+                                                         s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(), st))
+
+    def exchange_halo(self):
+        """First x/y row of the band above -> halo row of this band (MIDAS sub-grids only)."""
+        if self.world == 1 or self.halo == "recompute":
+            return
+        torch = self.torch
+        if self.halo == "local":
+            for s in self.plan.subs:
+                b = self.buf[s.name]
+                if b["needs_halo"]:
+                    up = self.peers[self.rank + 1].buf[s.name]
+                    b["x"][b["n"]].copy_(up["x"][0])
+                    b["y"][b["n"]].copy_(up["y"][0])
+            return
+        import torch.distributed as dist
+
+        ops = []
+        for s in self.plan.subs:
+            if s.kind not in ("mercator", "latlon"):
+                continue
+            b = self.buf[s.name]
+            if b["needs_halo"]:  # receive from the rank above
+                ops.append(dist.P2POp(dist.irecv, b["x"][b["n"]], self.rank + 1))
+                ops.append(dist.P2POp(dist.irecv, b["y"][b["n"]], self.rank + 1))
+            # send my first row to the rank below if IT needs a halo: it does iff it owns cell rows and is not the top band
+            if self.rank > 0 and b["n"] > 0:
+                lo_b, hi_b = band(s.nj1, self.rank - 1, self.world)
+                if min(hi_b, s.nj1 - 1) - lo_b > 0 and hi_b < s.nj1:
+                    ops.append(dist.P2POp(dist.isend, b["x"][0], self.rank - 1))
+                    ops.append(dist.P2POp(dist.isend, b["y"][0], self.rank - 1))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def phase_b(self):
+        """Metrics and angle of this rank's bands."""
+        p, st = self.plan, self._stream()
+        ni1 = p.Ni + 1
+        for s in p.subs:
+            b = self.buf[s.name]
+            if b["n"] == 0:
+                continue
+            if p.skip_metrics:
+                for f in ("dx", "dy", "area"):
+                    L.call("ogg_fill_dev", b[f].numel(), -1.0, b[f].data_ptr(), st)
+            if s.kind in ("mercator", "latlon"):
+                rows_xy = b["x"].shape[0]
+                if p.skip_metrics:
+                    self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", rows_xy, ni1, b["x"].data_ptr(), b["y"].data_ptr(),
+                                                          b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
+                else:
+                    self._timed("midas_angle", lambda: L.call("ogg_grid_metrics_midas_dev", rows_xy, ni1, b["x"].data_ptr(),
+                                                              b["y"].data_ptr(), b["n"], b["n_cell"], p.Re, 1, b["dx"].data_ptr(),
+                                                              b["dy"].data_ptr() if b["n_cell"] else None,
+                                                              b["area"].data_ptr() if b["n_cell"] else None,
+                                                              b["angle_dx"].data_ptr(), st))
+            else:
+                if not p.skip_metrics:
+                    if s.kind == "bipolar":
+                        self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
+                                                                   s.rp, p.Re, b["lo"], b["n"], b["n_cell"], b["dx"].data_ptr(),
+                                                                   b["dy"].data_ptr(), b["area"].data_ptr(), st))
+                    else:
+                        j0 = s.row0 + b["lo"]
+                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_dev", 4, p.Ni, s.Nj, p.lon0, s.lat0,
+                                                                 s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
+                                                                 b["dy"].data_ptr(), b["area"].data_ptr(), st))
+                self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
+                                                      b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
+
+    def step(self, time_kernels=False):
+        """One full pass of the hot path for this rank's bands; outputs stay in HBM."""
+        self._events = {} if time_kernels else None
+        self.phase_a()
+        self.exchange_halo()
+        self.phase_b()
+
+    def kernel_times_ms(self):
+        """Mean per-launch duration of each kernel over the events recorded since the last reset."""
+        self.torch.cuda.synchronize(self.device)
+        out = {}
+        for k, evs in (self._events or {}).items():
+            ts = [a.elapsed_time(b) for a, b in evs]
+            out[k] = {"launches": len(ts), "total_ms": float(sum(ts)), "mean_ms": float(sum(ts) / len(ts))}
+        return out
+
+    # -- results ---------------------------------------------------------------------------------------------
+    def bands_to_host(self):
+        """This rank's bands as numpy arrays (halo rows dropped): {sub: {field: array}}."""
+        out = {}
+        for s in self.plan.subs:
+            b = self.buf[s.name]
+            out[s.name] = {f: (b[f][: b["n"]] if f in ("x", "y") else b[f]).cpu().numpy() for f in FIELDS}
+        return out
+
+
+def stitch(plan, per_rank_bands):
+    """Concatenate the bands of all ranks per sub-grid, then stitch the sub-grids south -> north as OGG:1315-1365
+    (x, y, dx, angle_dx drop the southern piece's last row; dy, area are concatenated whole), then apply
+    --south_cutoff_row."""
+    subs = {}
+    for s in plan.subs:
+        subs[s.name] = {f: np.concatenate([bands[s.name][f] for bands in per_rank_bands], axis=0) for f in FIELDS}
+    g = None
+    for s in plan.subs:
+        piece = subs[s.name]
+        if g is None:
+            g = dict(piece)
+        else:
+            g = {f: np.concatenate((g[f] if f in ("dy", "area") else g[f][:-1, :], piece[f]), axis=0) for f in FIELDS}
+    jcut = plan.rows_cut()
+    if jcut > 0:
+        g = {f: g[f][jcut:, :] for f in FIELDS}
+    g["sub"] = subs
+    return g

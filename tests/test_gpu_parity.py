@@ -1,0 +1,381 @@
+"""GPU parity tests: every hot-path function of SURVEY 8(a), called through the C ABI (ctypes), against the oracle on
+the same inputs and against the committed golden fixtures (generated from the reference itself).
+
+Tolerances (fp64; BASELINE.json's north_star asks for max-abs coordinate diff < 1e-12 deg and area diff < 1e-6 m^2):
+the kernels follow the oracle's operation order with FMA contraction off, so the only differences are last-ulp
+differences between the device libm (ocml) and the host's (numpy: glibc / SVML).  What that noise floor does to each
+field was measured (DESIGN.md "Parity"); the bounds below are those measurements with margin:
+
+  coordinates x, y (all sub-grids)      1e-12 deg   (north_star bound; measured <= 2e-13)
+  bipolar x next to the symmetry        2e-11 deg   acos/asin are ill-conditioned there (App. C: 6e-12 at 1/8 deg)
+    meridian, y at the two pole points
+  MIDAS dx, dy                          rel 2e-15 + abs 1e-10 m
+  MIDAS area                            rel 5e-12   (cancellation in sin(phi[j+1])-sin(phi[j]): 1 ulp of sin moves the
+                                                    area by 3e-5 m^2 at 1/8 deg -- the 1e-6 m^2 target is below 1 ulp)
+  bipolar quadrature dx, dy, area       rel 5e-14
+  displaced-pole quadrature dx, dy      rel 5e-7    (finite differences of a 2e-6 rad arc with eps=1e-3 amplify 1 ulp
+                     area               rel 5e-7     of atan2 to 1e-9..1e-7 relative -- in the reference too)
+  angle_dx                              1e-10 deg away from singular points (pole rows)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ogg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL_COORD = 1e-12
+TOL_COORD_ILL = 2e-11
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def ogg(hip):
+    import ocean_model_grid_generator_amd.ocean_grid_generator as m
+    return m
+
+
+def maxabs(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def maxrel(a, b, floor=0.0):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor + 1e-300))) if a.size else 0.0
+
+
+def record(name, **vals):
+    REPORT[name] = vals
+    out = os.environ.get("OGG_PARITY_REPORT")
+    if out:
+        with open(out, "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def fvec():
+    return np.load(os.path.join(GOLD, "ref_functions.npz"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a1-a3: Mercator and lat-lon builders
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ni", [180, 1440, 5760, 11520])
+def test_mercator_axis(ogg, fvec, Ni):
+    phi = np.array([-66.85954725 * orc.PI_180, 64.05895973 * orc.PI_180])
+    ys = ogg.y_mercator_rounded(Ni, phi)
+    assert np.array_equal(ys, orc.y_mercator_rounded(Ni, phi))          # integers: exact
+    yf = ogg.y_mercator(Ni, phi)
+    assert maxrel(yf, orc.y_mercator(Ni, phi)) < 5e-16
+    got = ogg.phi_mercator(Ni, np.arange(ys[0], ys[1] + 1))
+    want = orc.phi_mercator(Ni, np.arange(ys[0], ys[1] + 1))
+    assert maxabs(got, want) < 5e-14
+    if "phiM_%d" % Ni in fvec:
+        assert np.array_equal(ys, fvec["ymr_%d" % Ni])
+        assert maxabs(got, fvec["phiM_%d" % Ni]) < 5e-14
+    record("phi_mercator_%d" % Ni, maxabs=maxabs(got, want))
+
+
+@pytest.mark.parametrize("even", [True, False])
+def test_generate_mercator_grid(ogg, even):
+    x, y = ogg.generate_mercator_grid(720, -66.85954725, 64.05895973, -300.0, 360, 1.0, True, even)
+    ox, oy = orc.generate_mercator_grid(720, -66.85954725, 64.05895973, -300.0, 360, 1.0, True, even)
+    assert np.array_equal(x, ox)                                         # i*360/Ni: exact arithmetic
+    assert maxabs(y, oy) < 5e-14
+
+
+def test_mercator_enhanced_equator(ogg):
+    x, y = ogg.generate_mercator_grid(1440, -68.0, 65.0, -300.0, 360, 2.0, True, False, enhanced_equatorial=4)
+    ox, oy = orc.generate_mercator_grid(1440, -68.0, 65.0, -300.0, 360, 2.0, True, False, enhanced_equatorial=4)
+    assert x.shape == ox.shape and maxabs(y, oy) < 1e-13 and np.array_equal(x, ox)
+
+
+def test_generate_latlon_grid(ogg, fvec):
+    x, y = ogg.generate_latlon_grid(24, 5, -300.0, 360, -78.0, 11.3, ensure_nj_even=True)
+    assert np.array_equal(x, fvec["ll_x"]) and np.array_equal(y, fvec["ll_y"])   # +,*,/ only: bit-exact
+    x, y = ogg.generate_latlon_grid(1440, 110, -300.0, 360, -78.0, 11.11590341532381, ensure_nj_even=False)
+    ox, oy = orc.generate_latlon_grid(1440, 110, -300.0, 360, -78.0, 11.11590341532381, ensure_nj_even=False)
+    assert np.array_equal(x, ox) and np.array_equal(y, oy)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a4, a16, a17: mdist, MIDAS metrics, angle
+# ---------------------------------------------------------------------------------------------------------------
+def test_mdist_exact(ogg, fvec):
+    assert np.array_equal(ogg.mdist(fvec["mdist_a"], fvec["mdist_b"]), fvec["mdist_out"])   # fmod is exact
+    assert np.array_equal(ogg.mdist(fvec["mdist_a"], -300.0), orc.mdist(fvec["mdist_a"], -300.0))
+
+
+def test_midas_golden_distorted_mesh(ogg, fvec):
+    x, y = fvec["md_x"], fvec["md_y"]
+    dx, dy, area = ogg.generate_grid_metrics_MIDAS(x, y)
+    assert maxrel(dx, fvec["md_dx"]) < 2e-15 and maxrel(dy, fvec["md_dy"]) < 2e-15
+    assert maxrel(area, fvec["md_area"]) < 5e-12
+    _, _, area2 = ogg.generate_grid_metrics_MIDAS(x, y, latlon_areafix=False)
+    assert maxrel(area2, fvec["md_area_nofix"]) < 5e-15
+    ang = ogg.angle_x(x, y)
+    assert maxabs(ang, fvec["md_angle"]) < 1e-12
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 65), (17, 64), (33, 257), (200, 1000)])
+def test_midas_ragged_shapes(ogg, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    nj, ni = shape
+    x = np.tile(-300 + np.arange(ni) * 360.0 / max(ni - 1, 1), (nj, 1)) + rng.normal(0, 0.05, shape)
+    y = np.tile(np.linspace(-80, 80, nj).reshape(nj, 1), (1, ni)) + rng.normal(0, 0.05, shape)
+    dx, dy, area = ogg.generate_grid_metrics_MIDAS(x, y)
+    odx, ody, oar = orc.generate_grid_metrics_MIDAS(x, y)
+    assert maxrel(dx, odx) < 2e-15 and maxrel(dy, ody) < 2e-15
+    assert maxabs(area, oar) <= 5e-12 * np.abs(oar).max()
+    assert maxabs(ogg.angle_x(x, y), orc.angle_x(x, y)) < 1e-11
+
+
+def test_midas_mercator_r8_band(ogg):
+    """The HBM-bound kernel at 1/8 degree width (5761 columns), 400 rows."""
+    xo, yo = orc.generate_mercator_grid(5760, -66.85954725, 64.05895973, -300.0, 360, 8.0, True, False)
+    xo, yo = np.ascontiguousarray(xo[1000:1400]), np.ascontiguousarray(yo[1000:1400])
+    dx, dy, area = ogg.generate_grid_metrics_MIDAS(xo, yo)
+    odx, ody, oar = orc.generate_grid_metrics_MIDAS(xo, yo)
+    record("midas_r8_band", dx=maxabs(dx, odx), dy=maxabs(dy, ody), area=maxabs(area, oar), area_rel=maxrel(area, oar))
+    assert maxrel(dx, odx) < 2e-15 and maxrel(dy, ody) < 2e-15 and maxrel(area, oar) < 5e-12
+    assert np.array_equal(ogg.angle_x(xo, yo), orc.angle_x(xo, yo))     # atan2(0, +) == 0 on a lat-lon mesh
+
+
+def test_angle_shape_error(ogg):
+    with pytest.raises(Exception, match="same shape"):
+        ogg.angle_x(np.zeros((3, 4)), np.zeros((3, 5)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a5-a9: bipolar cap
+# ---------------------------------------------------------------------------------------------------------------
+def test_bipolar_projection_golden_special_points(ogg, fvec):
+    lams, phis, hi, hj = ogg.bipolar_projection(fvec["bp_lamg"], fvec["bp_phig"], float(fvec["bp_lon_bp"]), float(fvec["bp_rp"]))
+    lamg, phig = fvec["bp_lamg"], fvec["bp_phig"]
+    pole = phig == 90.0
+    # exact special values the reference guarantees: symmetry meridians and the pole row
+    dl = lamg - float(fvec["bp_lon_bp"])
+    assert np.all(lams[dl == 90] == float(fvec["bp_lon_bp"]) + 90) and np.all(lams[dl == 270] == float(fvec["bp_lon_bp"]) + 270)
+    assert maxabs(lams[~pole], fvec["bp_lams"][~pole]) < TOL_COORD_ILL and maxabs(phis, fvec["bp_phis"]) < TOL_COORD_ILL
+    assert maxrel(hi, fvec["bp_hi"]) < 1e-12 and maxrel(hj, fvec["bp_hj"]) < 1e-12
+    hi2, hj2 = ogg.bipolar_projection(lamg, phig, float(fvec["bp_lon_bp"]), float(fvec["bp_rp"]), metrics_only=True)
+    assert np.array_equal(hi2, hi) and np.array_equal(hj2, hj)
+
+
+@pytest.mark.parametrize("Ni,Nj,lat0", [(48, 10, 64.05895973), (1440, 238, 64.97316302279852), (5760, 960, 64.03160594077568)])
+def test_bipolar_cap_mesh(ogg, fvec, Ni, Nj, lat0):
+    lams, phis, hi, hj = ogg.generate_bipolar_cap_mesh(Ni, Nj, lat0, -300.0, ensure_nj_even=False)
+    ol, op, ohi, ohj = orc.generate_bipolar_cap_mesh(Ni, Nj, lat0, -300.0, False)
+    # known answers
+    assert phis[-1, Ni // 4] == 90.0 and phis[-1, 3 * Ni // 4] == 90.0
+    assert np.all(lams[:, Ni // 4] == -300.0 + 90)
+    assert abs(phis[-1, 0] - lat0) < 1e-12 and abs(phis[-1, Ni // 2] - lat0) < 1e-12
+    d = np.abs(lams - ol)
+    ill = np.zeros(lams.shape, bool)
+    for c in (Ni // 4, 3 * Ni // 4):
+        ill[:, max(c - 2, 0):c + 3] = True                   # cells adjacent to the symmetry meridians
+    ill[-1, :] = True                                         # the fold row through the two poles
+    record("bp_mesh_%d" % Ni, x_all=float(d.max()), x_regular=float(d[~ill].max()), y=maxabs(phis, op),
+           frac_x_gt_1e12=float((d > 1e-12).mean()))
+    assert d[~ill].max() < TOL_COORD and d.max() < TOL_COORD_ILL
+    dy_ = np.abs(phis - op)
+    assert dy_[:-2].max() < TOL_COORD and dy_.max() < 1e-6   # the two pole points: acos at A -> 1 (App. C: 2e-7)
+    assert maxrel(hi, ohi) < 1e-11 and maxrel(hj, ohj) < 1e-11
+    if Ni == 48:
+        assert maxabs(lams, fvec["bpm_lams"]) < TOL_COORD_ILL and maxabs(phis, fvec["bpm_phis"]) < TOL_COORD_ILL
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_bipolar_quad_golden_small(ogg, fvec, order):
+    Ni, Nj, lat0 = int(fvec["bpm_Ni"]), int(fvec["bpm_Nj"]), float(fvec["bpm_lat0"])
+    dxq, dyq, daq = ogg.bipolar_cap_metrics_quad_fast(order, Ni, Nj, lat0, float(fvec["bp_lon_bp"]), float(fvec["bp_rp"]))
+    for a, k in ((dxq, "dx"), (dyq, "dy"), (daq, "da")):
+        assert maxrel(a, fvec["bpq%d_%s" % (order, k)]) < 5e-14, k
+
+
+def test_bipolar_quad_uncoded_order(ogg):
+    with pytest.raises(Exception, match="Uncoded order"):
+        ogg.bipolar_cap_metrics_quad_fast(6, 48, 10, 64.0, -300.0, 0.23)
+
+
+@pytest.mark.parametrize("Ni,Nj,lat0", [(1440, 238, 64.97316302279852), (333, 7, 70.0)])
+def test_bipolar_quad_vs_oracle(ogg, Ni, Nj, lat0):
+    rp = np.tan(0.5 * (90 - lat0) * orc.PI_180)
+    got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
+    want = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
+    record("bp_quad_%d" % Ni, dx=maxrel(got[0], want[0]), dy=maxrel(got[1], want[1]), area=maxrel(got[2], want[2]),
+           area_abs=maxabs(got[2], want[2]))
+    for g, w in zip(got, want):
+        assert maxrel(g, w) < 5e-14
+    # analytic self-check of the reference (OGG:732-770): % errors of sum(area), meridian arc, parallel arc, fold
+    err = orc.metrics_error(got[0], got[1], got[2], Ni, lat0, 90.0, bipolar=True)
+    oerr = orc.metrics_error(want[0], want[1], want[2], Ni, lat0, 90.0, bipolar=True)
+    assert max(abs(a - b) for a, b in zip(err, oerr)) < 1e-11
+    if Ni == 1440:
+        assert max(abs(e) for e in err) < 1e-9
+
+
+def test_bipolar_cap_ij_array(ogg):
+    rng = np.random.default_rng(5)
+    i, j = np.sort(rng.uniform(0, 48, 33)), np.sort(rng.uniform(0, 9.9, 7))
+    hi, hj = ogg.bipolar_cap_ij_array(i, j, 48, 10, 64.05895973, -300.0, 0.2313)
+    ohi, ohj = orc.bipolar_cap_ij_array(i, j, 48, 10, 64.05895973, -300.0, 0.2313)
+    assert maxrel(hi, ohi) < 1e-13 and maxrel(hj, ohj) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a10-a15: displaced-pole cap
+# ---------------------------------------------------------------------------------------------------------------
+def _dp(fvec):
+    return [int(fvec["dp_Ni"]), int(fvec["dp_Nj"]), float(fvec["dp_lon0"]), float(fvec["dp_lat0"]), float(fvec["dp_lon_dp"]),
+            float(fvec["dp_r_dp"])]
+
+
+def test_displaced_pole_grid_golden(ogg, fvec):
+    x, y, londp, latdp = ogg.generate_displaced_pole_grid(*_dp(fvec))
+    assert maxabs(x, fvec["dp_x"]) < TOL_COORD and maxabs(y, fvec["dp_y"]) < TOL_COORD
+    assert abs(londp - fvec["dp_pole"][0]) < TOL_COORD and abs(latdp - fvec["dp_pole"][1]) < TOL_COORD
+    assert np.all(np.abs(x[0, :] - (80.0 - 360)) < TOL_COORD)                    # pole row is (lon_dp-360, lat_dp)
+
+
+def test_displaced_pole_mesh_fractional_golden(ogg, fvec):
+    lam, phi, _, _ = ogg.displacedPoleCap_mesh(fvec["dpf_i"], fvec["dpf_j"], *_dp(fvec))
+    assert maxabs(lam, fvec["dpf_lam"]) < TOL_COORD and maxabs(phi, fvec["dpf_phi"]) < TOL_COORD
+    gad = ogg.great_arc_distance(fvec["dpf_j"], fvec["dpf_i"] + 1e-3, fvec["dpf_j"], fvec["dpf_i"] - 1e-3, *_dp(fvec))
+    assert maxrel(gad, fvec["dp_gad"]) < 5e-7
+
+
+@pytest.mark.parametrize("Ni,Nj,r_dp", [(1440, 140, 0.2), (720, 70, 0.34135899793333113), (5760, 560, 0.2)])
+def test_displaced_pole_grid_unwrap(ogg, Ni, Nj, r_dp):
+    """x must follow the sequential unwrap exactly: any wrong state would show as a 360 degree error."""
+    x, y, _, _ = ogg.generate_displaced_pole_grid(Ni, Nj, -300.0, -78.0, 80.0, r_dp)
+    ox, oy, _, _ = orc.generate_displaced_pole_grid(Ni, Nj, -300.0, -78.0, 80.0, r_dp)
+    record("dp_mesh_%d" % Ni, x=maxabs(x, ox), y=maxabs(y, oy))
+    assert maxabs(x, ox) < TOL_COORD and maxabs(y, oy) < TOL_COORD
+
+
+def test_monotonic_bounding_and_projection(ogg):
+    rng = np.random.default_rng(11)
+    v = rng.uniform(-180, 180, (9, 700))
+    v[:, 300:] = np.sort(v[:, 300:], axis=1)
+    want = orc.monotonic_bounding(v.copy(), -300.0)
+    got = ogg.monotonic_bounding(v.copy(), -300.0)
+    assert np.array_equal(got, want)                                              # comparisons and -360 only: bit-exact
+    lon = np.tile(-300 + np.arange(600) * 0.6, (5, 1))
+    lat = np.tile(np.linspace(-90, -78, 5).reshape(5, 1), (1, 600))
+    z0 = 0.2 * (np.cos(80 * orc.PI_180) + 1j * np.sin(80 * orc.PI_180))
+    rj = np.tan((90 - 78.0) * orc.PI_180)
+    lam, phi = ogg.displacedPoleCap_projection(lon, lat, z0, rj)
+    olam, ophi = orc.displacedPoleCap_projection(lon, lat, z0, rj)
+    assert maxabs(lam, olam) < TOL_COORD and maxabs(phi, ophi) < TOL_COORD
+    u, v2, du, dv = ogg.displacedPoleCap_baseGrid(np.arange(5.0), np.arange(4.0), 72, 14, -300.0, -78.0)
+    assert np.array_equal(u, -300.0 + np.arange(5.0) * 360.0 / 72.0) and np.array_equal(v2, -90.0 + np.arange(4.0) * 12.0 / 14.0)
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_displaced_pole_quad_golden_small(ogg, fvec, order):
+    got = ogg.displacedPoleCap_metrics_quad(order, *_dp(fvec))
+    for a, k in zip(got, ("dx", "dy", "da")):
+        want = fvec["dpq%d_%s" % (order, k)]
+        # row 0 is the pole itself (h -> 0): compare relative to the field's scale
+        assert maxabs(a, want) <= 5e-7 * np.abs(want).max(), (k, maxabs(a, want))
+
+
+def test_displaced_pole_quad_order_not_coded(ogg):
+    for order in (3, 5):
+        with pytest.raises(Exception, match="order not coded"):
+            ogg.displacedPoleCap_metrics_quad(order, 72, 14, -300.0, -78.0, 80.0, 0.2)
+    with pytest.raises(Exception, match="order not coded"):
+        ogg.numerical_hi(np.arange(3.0), np.arange(3.0), 72, 14, -300.0, -78.0, 80.0, 0.2, 1e-3, order=3)
+
+
+@pytest.mark.parametrize("Ni,Nj,r_dp", [(1440, 140, 0.2), (720, 70, 0.34135899793333113)])
+def test_displaced_pole_quad_vs_oracle(ogg, Ni, Nj, r_dp):
+    got = ogg.displacedPoleCap_metrics_quad(4, Ni, Nj, -300.0, -78.0, 80.0, r_dp)
+    want = orc.displacedPoleCap_metrics_quad(4, Ni, Nj, -300.0, -78.0, 80.0, r_dp)
+    jm = int(np.ceil(0.49 * Nj))
+    rel = [float(np.max(np.abs(g[jm:] - w[jm:]) / np.abs(w[jm:]))) for g, w in zip(got, want)]
+    record("dp_quad_%d" % Ni, dx_rel=rel[0], dy_rel=rel[1], area_rel=rel[2], area_abs=maxabs(got[2][jm:], want[2][jm:]))
+    assert max(rel) < 5e-7
+    for g, w in zip(got, want):                       # doughnut rows incl. the pole: relative to the field scale
+        assert maxabs(g, w) <= 5e-7 * np.abs(w).max()
+
+
+@pytest.mark.parametrize("fd", [2, 4, 6])
+def test_numerical_h(ogg, fvec, fd):
+    dp = _dp(fvec)
+    hi = ogg.numerical_hi(fvec["dpf_j"], fvec["dpf_i"], *dp, eps=1e-3, order=fd)
+    hj = ogg.numerical_hj(fvec["dpf_j"], fvec["dpf_i"], *dp, eps=1e-3, order=fd)
+    ohi = orc.numerical_hi(fvec["dpf_j"], fvec["dpf_i"], *dp, eps=1e-3, order=fd)
+    ohj = orc.numerical_hj(fvec["dpf_j"], fvec["dpf_i"], *dp, eps=1e-3, order=fd)
+    assert maxabs(hi, ohi) <= 5e-7 * np.abs(ohi).max() and maxabs(hj, ohj) <= 5e-7 * np.abs(ohj).max()
+    if fd == 6:
+        assert maxabs(hi, fvec["dp_hi6"]) <= 5e-7 * np.abs(ohi).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole supergrid through main(): golden fixtures of the reference's own test configurations
+# ---------------------------------------------------------------------------------------------------------------
+FIELD_TOL = {  # (abs, rel) per stitched field; see the module docstring
+    "x": (TOL_COORD_ILL, 0.0), "y": (1e-6, 0.0), "dx": (2e-6, 5e-7), "dy": (2e-6, 5e-7), "area": (2e-2, 5e-7), "angle_dx": (None, None),
+}
+
+
+def _check_supergrid(got, want, name):
+    rep = {}
+    for f in ("x", "y", "dx", "dy", "area"):
+        assert got[f].shape == want[f].shape, (f, got[f].shape, want[f].shape)
+        d = np.abs(got[f] - want[f])
+        rep[f] = float(d.max())
+        a, r = FIELD_TOL[f]
+        assert np.all(d <= a + r * np.abs(want[f])), (name, f, rep[f])
+    # angle_dx is noise at singular points (the two bipolar pole points, the displaced pole): compare where the
+    # argument of atan2 is well-conditioned, i.e. everywhere except a few points; demand 99.9 % within 1e-9 deg
+    d = np.abs(got["angle_dx"] - want["angle_dx"])
+    d = np.minimum(d, np.abs(d - 360.0))
+    rep["angle_dx_p999"] = float(np.quantile(d, 0.999))
+    assert rep["angle_dx_p999"] < 1e-9, (name, rep)
+    record("supergrid_" + name, **rep)
+
+
+@pytest.mark.parametrize("name", ["r0.25_even", "r0.5_dp"])
+def test_main_vs_reference_golden(ogg, name, tmp_path):
+    flags = json.load(open(os.path.join(GOLD, "ref_hashes.json")))["configs"][name]["flags"]
+    want = np.load(os.path.join(GOLD, "ref_small_%s.npz" % name))
+    out = tmp_path / "g.nc"
+    got = ogg.main(gridfilename=str(out), no_changing_meta=True, return_arrays=True, **flags)
+    _check_supergrid(got, want, name)
+    # the file holds the same arrays, in the reference's layout (OGG:795-821)
+    from scipy.io import netcdf_file
+    nc = netcdf_file(str(out), "r", mmap=False)
+    assert list(nc.dimensions.keys()) == ["nyp", "nxp", "ny", "nx", "string"]
+    assert list(nc.variables.keys()) == ["tile", "y", "x", "dy", "dx", "area", "angle_dx"]
+    assert nc.version_byte == 2 and nc.variables["area"].units == b"m2" and nc.variables["dx"].units == b"meters"
+    assert b"".join(nc.variables["tile"][:5]) == b"tile1"
+    for f in ("x", "y", "dx", "dy", "area", "angle_dx"):
+        assert np.array_equal(nc.variables[f][:], got[f])
+    nc.close()
+
+
+@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r2_equenh4", "r2_skip_metrics", "r0.5_latdp", "r1_dp_cutang", "r1_matchdy"])
+def test_main_vs_oracle(ogg, name):
+    cfg = json.load(open(os.path.join(GOLD, "ref_hashes.json")))["configs"][name]
+    flags = dict(cfg["flags"])
+    got = ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, **flags)
+    for f, shp in cfg["shapes"].items():
+        assert list(got[f].shape) == shp, (f, got[f].shape, shp)          # shapes pinned by the reference run
+    r = flags.pop("inverse_resolution")
+    want = orc.make_supergrid(r, **flags)
+    _check_supergrid(got, want, name)
+
+
+def test_main_rejects_bad_flags(ogg):
+    with pytest.raises(SystemExit):
+        ogg.main(1.0, gridfilename=None, r_dp=0.2, lat_dp=-85.0)
+    with pytest.raises(SystemExit):
+        ogg.main(1.0, gridfilename=None, match_dy=["sc"])
