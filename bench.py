@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: supergrid cells/s (coordinates + metrics) of the 1/8 degree tripolar grid on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload r8|r8_latdp|r4_om4|r16|r2]
+
+A step is one full pass of the hot path over the whole supergrid (all sub-grids: axes, coordinate tiles / meshes, halo
+exchange, MIDAS metrics + angle, cap quadratures), inputs being ~10 scalars, outputs (six fp64 fields) left in HBM.
+For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL); every sub-grid is split into N latitude bands and
+the total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the kernel with the largest share of the step, priced as HBM traffic: algorithmic bytes per launch /
+                mean launch duration (HIP events on the launch stream, inside the timed region) against 8 TB/s
+  kernels       the same for every kernel of the step (the cap quadratures are fp64-VALU bound: their HBM fraction is
+                small by construction)
+  cpu_baseline  the numpy oracle (a port of the reference's algorithm, 1 core like the reference) on a bounded sample
+                of the same workload: the southernmost 1/sample_div of the rows of every sub-grid
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "r8": dict(inverse_resolution=8.0),                                              # BASELINE.json configs[2]
+    "r8_latdp": dict(inverse_resolution=8.0, lon_dp=80.0, lat_dp=-85.85),            # configs[3] (valid spelling)
+    "r4_om4": dict(inverse_resolution=4.0, r_dp=0.2, south_cutoff_row=83),           # configs[1]
+    "r16": dict(inverse_resolution=16.0),                                            # configs[4]
+    "r2": dict(inverse_resolution=2.0),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+# algorithmic HBM bytes per output unit of each kernel: reads + writes that any implementation must do
+ALG_BYTES = {
+    "tile_latlon": ("point", 16),     # x, y written once
+    "midas_angle": ("point", 48),     # x, y read (16 B) + dx, dy, area, angle_dx written (32 B)
+    "angle_x": ("point", 24),         # x, y read + angle_dx written
+    "bipolar_mesh": ("point", 16),
+    "bipolar_quad": ("point", 24),    # dx, dy, area written; no reads
+    "dpole_mesh": ("point", 16),
+    "dpole_quad": ("point", 24),
+}
+
+
+def band_points(plan, rank, world, sg_mod):
+    """points handled per launch by each kernel on this rank (for pricing launches in bytes)."""
+    ni1 = plan.Ni + 1
+    pts = {}
+    for s in plan.subs:
+        lo, hi = sg_mod.band(s.nj1, rank, world)
+        n = (hi - lo) * ni1
+        if s.kind in ("mercator", "latlon"):
+            pts.setdefault("tile_latlon", []).append(n)
+            pts.setdefault("midas_angle", []).append(n)
+        elif s.kind == "bipolar":
+            pts.setdefault("bipolar_mesh", []).append(n)
+            pts.setdefault("bipolar_quad", []).append(n)
+            pts.setdefault("angle_x", []).append(n)
+        else:
+            pts.setdefault("dpole_mesh", []).append(n)
+            pts.setdefault("dpole_quad", []).append(n)
+            pts.setdefault("angle_x", []).append(n)
+    return pts
+
+
+def cpu_baseline(flags, sample_div):
+    """Oracle timed on the southernmost 1/sample_div of the rows of every sub-grid (1 thread, like the reference)."""
+    from oracle import ogg_oracle as orc
+
+    r = flags["inverse_resolution"]
+    Ni = int(r * 2 * 360)
+    q = Ni // 4
+    t0 = time.perf_counter()
+    cells = 0
+    phi_s, phi_n = (-68.0, 65.0) if r == 2 else (-66.85954725, 64.05895973)
+    y0, y1 = orc.mercator_y_star(Ni, phi_s, phi_n, True, False)
+    phi_M = orc.phi_mercator(Ni, np.arange(y0, y1 + 1))
+    lam = -300.0 + np.arange(Ni + 1) * 360 / float(Ni)
+
+    def latlon_band(axis):
+        n = max((axis.size - 1) // sample_div, 1)
+        x = np.tile(lam, (n + 1, 1))
+        y = np.tile(axis[: n + 1].reshape(-1, 1), (1, Ni + 1))
+        orc.generate_grid_metrics_MIDAS(x, y)
+        orc.angle_x(x, y)
+        return n * Ni
+
+    cells += latlon_band(phi_M)
+    lat0_bp = phi_M[-1]
+    Nj = int(60 * r * 2) if r != 2 else 238
+    n = max(Nj // sample_div, 1)
+    lon_g = -300.0 + np.arange(Ni + 1) * 360.0 / float(Ni)
+    latg = lat0_bp + np.arange(n + 1) * (90 - lat0_bp) / float(Nj)
+    rp = np.tan(0.5 * (90 - lat0_bp) * orc.PI_180)
+    lams, phis, _, _ = orc.bipolar_projection(np.tile(lon_g, (n + 1, 1)), np.tile(latg.reshape(-1, 1), (1, Ni + 1)), -300.0, rp)
+    orc.angle_x(lams, phis)
+    orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0_bp, -300.0, rp, rows_per_chunk=16, j_last=n)
+    cells += n * Ni
+    latUp = phi_M[0]
+    so_axis = -78.0 + np.arange(int(r * 55) + 1) * (latUp + 78.0) / float(int(r * 55))
+    cells += latlon_band(so_axis)
+    if flags.get("lat_dp", -99.0) > -90 or flags.get("r_dp", 0.0) != 0.0:
+        Njs = int(r * 40) * 7 // 4
+        r_dp = flags.get("r_dp", 0.0)
+        if flags.get("lat_dp", -99.0) > -90:
+            r_dp = np.tan((90 + flags["lat_dp"]) * orc.PI_180) / np.tan((90 - 78.0) * orc.PI_180)
+        jm = int(np.ceil(0.49 * Njs))
+        jm += jm % 2
+        n = max((Njs - jm) // sample_div, 1)
+        x, y, _, _ = orc.displacedPoleCap_mesh(np.arange(Ni + 1), np.arange(jm, jm + n + 1), Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp)
+        orc.angle_x(x, y)
+        orc.displacedPoleCap_metrics_quad(4, Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp, rows_per_chunk=8, j_first=jm, j_last=jm + n)
+        cells += n * Ni
+    else:
+        Njs = int((-78.0 + 90.0) / (1.0 / r / 2))
+        sc_axis = -90.0 + np.arange(Njs + 1) * 12.0 / float(Njs)
+        cells += latlon_band(sc_axis)
+    dt = time.perf_counter() - t0
+    return cells, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="r8", choices=sorted(WORKLOADS))
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "recompute"])
+    ap.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline runs 1/div of the rows of every sub-grid (0: skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    from ocean_model_grid_generator_amd import _lib, supergrid
+
+    flags = WORKLOADS[args.workload]
+    plan = supergrid.SupergridPlan(**flags)
+    sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sg.step()
+    sync()
+    sg._events = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sg.phase_a()
+        sg.exchange_halo()
+        sg.phase_b()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ktimes = sg.kernel_times_ms()
+
+    if rank == 0:
+        pts = band_points(plan, rank, world, supergrid)
+        kernels = {}
+        for k, v in ktimes.items():
+            unit, b = ALG_BYTES[k]
+            launches_per_step = len(pts[k])
+            alg_bytes = b * float(sum(pts[k])) / launches_per_step      # mean algorithmic bytes per launch
+            gbs = alg_bytes / (v["mean_ms"] * 1e-3) / 1e9
+            kernels[k] = {"launches_per_step": launches_per_step, "mean_ms": round(v["mean_ms"], 5),
+                          "ms_per_step": round(v["total_ms"] / args.steps, 5), "alg_bytes_per_launch": int(alg_bytes),
+                          "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+        out = {
+            "metric": "supergrid cells/sec (coords+metrics)", "value": plan.cells * args.steps / dt, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
+                       "flags": flags, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
+                       "parallelism": "latitude bands x%d per sub-grid, halo=%s" % (world, args.halo if world > 1 else "none")},
+            "device": _lib.device_name(),
+            "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
+                         "note": "cap quadratures are fp64-VALU bound (DESIGN.md); midas_angle is the HBM-bound kernel"},
+            "kernels": kernels,
+        }
+        if world == 1 and args.cpu_sample_div > 0:
+            cells, cdt = cpu_baseline(flags, args.cpu_sample_div)
+            out["cpu_baseline"] = {"value": cells / cdt, "unit": "cells/s", "cores": 1, "kind": "port",
+                                   "sample": "numpy oracle on the southernmost 1/%d of the rows of every sub-grid of the same "
+                                             "workload: %d cells in %.1f s" % (args.cpu_sample_div, cells, cdt),
+                                   "host_cpus": os.cpu_count()}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

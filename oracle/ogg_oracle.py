@@ -367,10 +367,12 @@ def bipolar_cap_ij_array(i, j, Ni, Nj_ncap, lat0_bp, lon_bp, rp):
     return h_i_inv, h_j_inv
 
 
-def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=RE_DEFAULT, rows_per_chunk=64):
+def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=RE_DEFAULT, rows_per_chunk=64, j_first=0,
+                                  j_last=None):
     """dx (ny+1,nx), dy (ny,nx+1), area (ny,nx) by Lobatto quadrature of h.  OGG:136-188.
     Evaluated in chunks of cell rows; the per-element arithmetic and the summation order are the
-    reference's (the reference's own chunking, OGG:161-172, is likewise semantically irrelevant)."""
+    reference's (the reference's own chunking, OGG:161-172, is likewise semantically irrelevant).  ``j_first`` /
+    ``j_last`` restrict the evaluation to cell rows [j_first, j_last) (others stay zero): cells are independent."""
     quad_positions(order)  # raises for uncoded orders
     # OGG:145-147: only the LAST node of a cell is tested against ny (hits cell ny-1 only)
     nodes = _lattice_1d(ny, order).reshape(ny + 1, order)
@@ -380,8 +382,9 @@ def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=RE_DEFA
     daq = np.zeros([ny + 1, nx + 1])
     dxq = np.zeros([ny + 1, nx + 1])
     dyq = np.zeros([ny + 1, nx + 1])
-    for c0 in range(0, ny + 1, rows_per_chunk):
-        c1 = min(ny + 1, c0 + rows_per_chunk)
+    j_end = ny + 1 if j_last is None else min(j_last, ny + 1)
+    for c0 in range(j_first, j_end, rows_per_chunk):
+        c1 = min(j_end, c0 + rows_per_chunk)
         dx, dy = bipolar_cap_ij_array(i1d, j1d[c0 * order:c1 * order], nx, ny, lat0_bp, lon_bp, rp)
         dx_r = dx.reshape(c1 - c0, order, nx + 1, order)
         dy_r = dy.reshape(c1 - c0, order, nx + 1, order)
@@ -478,7 +481,7 @@ def numerical_hj(j, i, nx, ny, lon0, lat0, lon_dp, r_dp, eps, order=6):
 
 
 def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=RE_DEFAULT, rows_per_chunk=32,
-                                  j_first=0):
+                                  j_first=0, j_last=None):
     """dx (ny+1,nx), dy (ny,nx+1), area (ny,nx) by quadrature of finite-difference h.  OGG:565-601.
     Cell rows are independent (the unwrap scan runs along i inside a lattice row), so the evaluation is
     chunked by cell rows; ``j_first`` skips cell rows < j_first (left as zeros) -- the rows main() discards
@@ -489,8 +492,9 @@ def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=RE
     daq = np.zeros([ny + 1, nx + 1])
     dxq = np.zeros([ny + 1, nx + 1])
     dyq = np.zeros([ny + 1, nx + 1])
-    for c0 in range(j_first, ny + 1, rows_per_chunk):
-        c1 = min(ny + 1, c0 + rows_per_chunk)
+    j_end = ny + 1 if j_last is None else min(j_last, ny + 1)
+    for c0 in range(j_first, j_end, rows_per_chunk):
+        c1 = min(j_end, c0 + rows_per_chunk)
         jj = j1d[c0 * order:c1 * order]
         dx = numerical_hi(jj, i1d, nx, ny, lon0, lat0, lon_dp, r_dp, eps=1e-3, order=order)
         dy = numerical_hj(jj, i1d, nx, ny, lon0, lat0, lon_dp, r_dp, eps=1e-3, order=order)
