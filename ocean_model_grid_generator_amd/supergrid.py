@@ -47,7 +47,9 @@ class SupergridPlan(object):
     latitudes are read back from device-computed values, exactly as main() reads them from phiMerc."""
 
     def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0,
-                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, Re=ogg._default_Re):
+                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, Re=ogg._default_Re, mercator_axis=None):
+        """``mercator_axis`` = (y0, phi_M) lets a caller that already holds the Mercator ordinate range and axis skip the
+        two device calls (the CPU tests of the band / halo logic pass values computed elsewhere)."""
         refineS, refineR = 2, inverse_resolution
         self.Re = Re
         self.skip_metrics = skip_metrics
@@ -59,13 +61,16 @@ class SupergridPlan(object):
         if refineR == 2:
             phi_s, phi_n = -68.0, 65.0
         # Mercator ordinate range: device y_mercator_rounded + host parity fixes (OGG:318-334)
-        ys = ogg.y_mercator_rounded(Ni, np.array([phi_s * ogg.PI_180, phi_n * ogg.PI_180]))
-        y0, y1 = int(ys[0]), int(ys[1])
-        if y0 % 2 == 0:
-            y0, y1 = y0 - 1, y1 - 1
-        if (y1 - y0 + 1) % 2 == 0 and ensure_nj_even:
-            y1 -= 1
-        phi_M = ogg.phi_mercator(Ni, np.arange(y0, y1 + 1))
+        if mercator_axis is None:
+            ys = ogg.y_mercator_rounded(Ni, np.array([phi_s * ogg.PI_180, phi_n * ogg.PI_180]))
+            y0, y1 = int(ys[0]), int(ys[1])
+            if y0 % 2 == 0:
+                y0, y1 = y0 - 1, y1 - 1
+            if (y1 - y0 + 1) % 2 == 0 and ensure_nj_even:
+                y1 -= 1
+            phi_M = ogg.phi_mercator(Ni, np.arange(y0, y1 + 1))
+        else:
+            y0, phi_M = int(mercator_axis[0]), np.asarray(mercator_axis[1], dtype=np.float64)
         if np.searchsorted(phi_M, 0.0) == 0:
             raise Exception("   Ooops: Equator is not in the grid")
         skipM = 1 if (phi_M.size % 2 == 0 and ensure_nj_even) else 0
@@ -146,7 +151,10 @@ class Supergrid(object):
         self.buf = {}
         self.timings = {}
         ni1 = plan.Ni + 1
-        with torch.cuda.device(self.device):
+        # device "cpu" allocates the same band buffers in host memory: only the partition and the halo exchange can
+        # run there (tests over gloo); the phases need a GPU
+        import contextlib
+        with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
             self.lon1d = torch.empty(ni1, dtype=torch.float64, device=self.device)
             for s in plan.subs:
                 lo, hi = band(s.nj1, rank, world)
@@ -166,6 +174,8 @@ class Supergrid(object):
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def _stream(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("the supergrid phases run on a GPU only (there is no CPU compute path)")
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
     @staticmethod
