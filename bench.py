@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 # algorithmic HBM bytes per output unit of each kernel: reads + writes that any implementation must do
 ALG_BYTES = {
+    "latlon_fused": ("point", 48),    # all six fields written once, nothing read
     "tile_latlon": ("point", 16),     # x, y written once
     "midas_angle": ("point", 48),     # x, y read (16 B) + dx, dy, area, angle_dx written (32 B)
     "angle_x": ("point", 24),         # x, y read + angle_dx written
@@ -56,6 +57,7 @@ def band_points(plan, rank, world, sg_mod):
         lo, hi = sg_mod.band(s.nj1, rank, world)
         n = (hi - lo) * ni1
         if s.kind in ("mercator", "latlon"):
+            pts.setdefault("latlon_fused", []).append(n)
             pts.setdefault("tile_latlon", []).append(n)
             pts.setdefault("midas_angle", []).append(n)
         elif s.kind == "bipolar":
@@ -131,7 +133,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="r8", choices=sorted(WORKLOADS))
-    ap.add_argument("--halo", default="rccl", choices=["rccl", "recompute"])
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "recompute"], help="halo source of the stencil pipeline")
+    ap.add_argument("--latlon", default="fused", choices=["fused", "stencil"],
+                    help="fused: lat-lon sub-grids from their 1-D axes in one kernel (no reads, no halo); stencil: tile, RCCL halo, "
+                         "generic 2x3-stencil kernel")
     ap.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline runs 1/div of the rows of every sub-grid (0: skip)")
     args = ap.parse_args()
 
@@ -154,7 +159,7 @@ def main():
 
     flags = WORKLOADS[args.workload]
     plan = supergrid.SupergridPlan(**flags)
-    sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo)
+    sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
 
     def sync():
         torch.cuda.synchronize()
@@ -201,7 +206,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
-                       "parallelism": "latitude bands x%d per sub-grid, halo=%s" % (world, args.halo if world > 1 else "none")},
+                       "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
+                           world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
             "device": _lib.device_name(),
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

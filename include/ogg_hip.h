@@ -95,6 +95,14 @@ int ogg_grid_metrics_midas(long nj1, long ni1, const double* x, const double* y,
 /* angle_x(x, y): angle_dx (nj1 x ni1), degrees */
 int ogg_angle_x(long nj1, long ni1, const double* x, const double* y, double* angle_dx);
 
+/* Fused builder for sub-grids that are lat-lon by construction (x[j][i] = lon1d[i], y[j][i] = lat1d[j]): writes x, y,
+ * angle_dx (n_pt_rows x ni1), dx (n_pt_rows x ni1-1) and dy (n_cell_rows x ni1), area (n_cell_rows x ni1-1) from the two
+ * 1-D axes alone; bit-identical to ogg_tile_latlon_dev + ogg_grid_metrics_midas_dev.  lat1d must hold n_pt_rows entries,
+ * plus one more when n_cell_rows == n_pt_rows (the row above the band).  metrics = 0 writes only x, y, angle_dx. */
+int ogg_latlon_supergrid_dev(long n_pt_rows, long n_cell_rows, long ni1, const double* lat1d, const double* lon1d, double Re,
+                             int metrics, double* x, double* y, double* dx, double* dy, double* area, double* angle,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Murray bipolar Arctic cap
  * ---------------------------------------------------------------------------------------------------- */

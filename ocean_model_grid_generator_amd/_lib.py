@@ -78,6 +78,8 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p],
     "ogg_monotonic_bounding": [c_long, c_long, c_void_p, c_double],
     "ogg_monotonic_bounding_dev": [c_long, c_long, c_void_p, c_double, c_void_p],
+    "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],
     "ogg_event_create": [ctypes.POINTER(c_void_p)],
     "ogg_event_destroy": [c_void_p],

@@ -141,11 +141,16 @@ class Supergrid(object):
     device-to-device; used to test the band logic on a single GPU) or "recompute" (the halo row of a lat-lon sub-grid is
     re-tiled from the 1-D axis every rank already holds; bitwise identical)."""
 
-    def __init__(self, plan, rank=0, world=1, device="cuda:0", halo="rccl", peers=None):
+    def __init__(self, plan, rank=0, world=1, device="cuda:0", halo="rccl", peers=None, latlon="fused"):
+        """``latlon``: how the sub-grids that are lat-lon by construction (Mercator, Southern Ocean, regular southern
+        cap) are produced.  "fused" (default): one kernel writes all six fields from the two 1-D axes -- 48 B written per
+        cell, nothing read, and no halo (every rank holds the whole 1-D axis).  "stencil": tile x, y; exchange the halo
+        row; run the generic 2x3-stencil kernel that reads x, y back -- the kernel the drop-in functions use for arbitrary
+        meshes.  Both give the same bits."""
         import torch
 
         self.torch = torch
-        self.plan, self.rank, self.world, self.halo = plan, rank, world, halo
+        self.plan, self.rank, self.world, self.halo, self.latlon = plan, rank, world, halo, latlon
         self.device = torch.device(device)
         self.peers = peers  # halo="local": list of all virtual ranks' Supergrid objects
         self.buf = {}
@@ -160,7 +165,7 @@ class Supergrid(object):
                 lo, hi = band(s.nj1, rank, world)
                 n = hi - lo
                 n_cell = min(hi, s.nj1 - 1) - lo  # cell rows owned (a cell row j belongs to the owner of point row j)
-                needs_halo = s.kind in ("mercator", "latlon") and n_cell > 0 and hi < s.nj1
+                needs_halo = latlon == "stencil" and s.kind in ("mercator", "latlon") and n_cell > 0 and hi < s.nj1
                 b = {"lo": lo, "hi": hi, "n": n, "n_cell": max(n_cell, 0), "needs_halo": needs_halo}
                 rows_xy = n + (1 if needs_halo else 0)
                 for f, (r, c) in (("x", (rows_xy, ni1)), ("y", (rows_xy, ni1)), ("dx", (n, ni1 - 1)), ("dy", (b["n_cell"], ni1)),
@@ -211,6 +216,13 @@ class Supergrid(object):
                     L.call("ogg_mercator_axis_dev", p.Ni, s.y0, s.n_axis, b["axis"].data_ptr(), st)
                 else:
                     L.call("ogg_linear_axis_dev", s.lnj + 1, s.lat0, s.lenlat, float(s.lnj), b["axis"].data_ptr(), st)
+                if self.latlon == "fused":
+                    self._timed("latlon_fused", lambda: L.call(
+                        "ogg_latlon_supergrid_dev", b["n"], b["n_cell"], ni1, self._p(b["axis"], s.row0 + b["lo"]), self.lon1d.data_ptr(),
+                        p.Re, 0 if p.skip_metrics else 1, b["x"].data_ptr(), b["y"].data_ptr(), b["dx"].data_ptr(),
+                        b["dy"].data_ptr() if b["n_cell"] else None, b["area"].data_ptr() if b["n_cell"] else None,
+                        b["angle_dx"].data_ptr(), st))
+                    continue
                 rows = b["n"] + (1 if (b["needs_halo"] and self.halo == "recompute") else 0)
                 self._timed("tile_latlon", lambda: L.call("ogg_tile_latlon_dev", rows, ni1, self._p(b["axis"], s.row0 + b["lo"]),
                                                           self.lon1d.data_ptr(), b["x"].data_ptr(), b["y"].data_ptr(), st))
@@ -223,7 +235,7 @@ class Supergrid(object):
 
     def exchange_halo(self):
         """First x/y row of the band above -> halo row of this band (MIDAS sub-grids only)."""
-        if self.world == 1 or self.halo == "recompute":
+        if self.world == 1 or self.halo == "recompute" or self.latlon == "fused":
             return
         torch = self.torch
         if self.halo == "local":
@@ -265,6 +277,8 @@ class Supergrid(object):
             if p.skip_metrics:
                 for f in ("dx", "dy", "area"):
                     L.call("ogg_fill_dev", b[f].numel(), -1.0, b[f].data_ptr(), st)
+            if s.kind in ("mercator", "latlon") and self.latlon == "fused":
+                continue  # all six fields were written in phase A
             if s.kind in ("mercator", "latlon"):
                 rows_xy = b["x"].shape[0]
                 if p.skip_metrics:

@@ -20,10 +20,10 @@ def sg(hip):
     return m
 
 
-def run(sg, plan, world=1, halo="local"):
+def run(sg, plan, world=1, halo="local", latlon="stencil"):
     ranks = []
     for r in range(world):
-        ranks.append(sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo=halo, peers=ranks))
+        ranks.append(sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo=halo, peers=ranks, latlon=latlon))
     for g in ranks:
         g.phase_a()
     for g in ranks:
@@ -67,6 +67,17 @@ def test_band_decomposition_is_bit_invariant(sg, name, world, halo):
         assert np.array_equal(one[f], many[f]), (f, world, halo)
 
 
+@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r2_skip_metrics", "r0.5_dp", "r0.25_even"])
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_fused_latlon_kernel_is_bit_identical_to_stencil(sg, name, world):
+    """The fused lat-lon kernel (no HBM reads, no halo) against tile + generic stencil kernel, sharded or not."""
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    stencil = run(sg, plan, 1, latlon="stencil")
+    fused = run(sg, plan, world, latlon="fused")
+    for f in FIELDS:
+        assert np.array_equal(stencil[f], fused[f]), (f, world)
+
+
 def test_more_ranks_than_rows(sg):
     """Tiny sub-grids: some ranks own no rows of a sub-grid, the top band may own only the fold row."""
     plan = sg.SupergridPlan(0.25, ensure_nj_even=True)
@@ -92,7 +103,10 @@ def test_full_size_properties_r8(sg):
     along the symmetry meridian, exact special values."""
     plan = sg.SupergridPlan(8.0)
     assert (plan.nyp, plan.Ni + 1) == (4393, 5761) and plan.cells == 4392 * 5760
-    g = run(sg, plan)
+    g = run(sg, plan, latlon="fused")
+    g2 = run(sg, plan, latlon="stencil")
+    for f in FIELDS:
+        assert np.array_equal(g[f], g2[f]), f
     Ni = plan.Ni
     sub = g["sub"]
     m = sub["Merc"]
@@ -114,8 +128,10 @@ def test_full_size_properties_r8(sg):
     ycol = g["y"][:, Ni // 4]
     assert np.all(np.diff(ycol) > 0) and ycol[-1] == 90.0 and ycol[0] == -90.0
     assert np.searchsorted(ycol, 0.0) % 2 == 1
-    # dy is exactly 0 at the three fold points i = 0, Ni/2, Ni of the last bipolar cell row -- in the reference too
-    assert np.all(g["dx"] > 0) and np.all(g["dy"] >= 0) and (g["dy"] == 0).sum() <= 3 and np.all(g["area"] > 0)
+    # the bipolar h_j vanishes identically on the meridians i = 0, Ni/2, Ni (alpha2 == 1, OGG:81-84) -- in the
+    # reference too -- so dy is exactly 0 there and positive everywhere else
+    zc = np.unique(np.argwhere(g["dy"] == 0)[:, 1])
+    assert np.all(g["dx"] > 0) and np.all(g["dy"] >= 0) and set(zc.tolist()) <= {0, Ni // 2, Ni} and np.all(g["area"] > 0)
     assert np.all(np.abs(g["angle_dx"]) <= 180.0)
     # dy is continuous across the Mercator / bipolar joint along the symmetry meridian (OGG:1027-1030)
     jM = sub["SC"]["y"].shape[0] + sub["SO"]["y"].shape[0] + sub["Merc"]["y"].shape[0] - 3
