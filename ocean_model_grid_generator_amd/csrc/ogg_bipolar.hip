@@ -9,6 +9,8 @@
 // projection into its row-only part (5 libm calls per lattice row), its column-only part (sincos + fmod per
 // lattice column) and the per-point remainder.  Each thread then reduces one cell from LDS in the reference's
 // summation order (OGG:216-221, 246-253).  The full lattice (138 M points at 1/8 degree) is never materialised.
+#include <cstdlib>
+
 #include "ogg_common.h"
 #include "ogg_math.h"
 
@@ -74,6 +76,32 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
     if (huge) hi = MM;
     h_i_inv = sqrt(hi);
     rden_out = rden;
+}
+
+// Algebraically reduced form of bp_point for the quadrature lattice (metrics only).  With A = sinla*sphig in [0,1]:
+//   tan(acos(A)/2)^2 = (1-A)/(1+A),   1 + (rp t)^2 = D/(1+A),  D = (1+A) + rp^2 (1-A)
+//   M_inv = rp (1+t^2) / (1+(rp t)^2) = 2 rp / D
+//   cos^2(phis PI/180) = sin^2(2 atan(rp t)) = 4 rp^2 (1-A)(1+A) / D^2
+// so the acos -> tan -> atan -> cos round trip of OGG:69-79 collapses to one division.  The identities are exact; the
+// results differ from the literal sequence only by rounding: <= 1e-14 relative where the cap latitude is >= 1.4 degrees
+// from the pole (measured against the oracle on the 1/8 degree lattice; 4e-15 at >= 4 degrees).  Nearer the pole the
+// LITERAL sequence loses digits (phis = 90 - small is rounded to 1 ulp of 90 before the cosine), and parity with the
+// reference means reproducing that, so lattice rows within OGG_BP_ALG_GAP_DEG (default 2) of the pole keep bp_point.
+OGG_DEV void bp_point_fast(const BpRow& r, const BpCol& c, double rp2x4, double rp2, double& h_i_inv, double& h_j_inv) {
+    const double a = c.alpha2, b = r.beta2_inv;
+    const double a1 = 1 - a, b1 = 1 + b;
+    const double rden = 1.0 / (1.0 + a * b);
+    const double A = c.sinla * r.sphig;
+    const double p1 = 1 + A, m1 = 1 - A;
+    const double E = 1.0 / (p1 + rp2 * m1);
+    const double MM = rp2x4 * (E * E);            // M_inv^2
+    const double cc = MM * (m1 * p1);             // cos^2(phis)
+    const double rr = rden * rden;
+    double hj = cc * a * a1 * b * b1 * rr + MM * a1 * rden;
+    double hi = cc * b1 * rr + MM * a * b * rden;
+    if (fabs(b) > kHuge) hj = hi = MM;
+    h_j_inv = sqrt(hj) * r.N_inv;
+    h_i_inv = sqrt(hi);
 }
 
 // lams of OGG:50-64
@@ -144,6 +172,7 @@ struct QuadParams {
     long n_cell_rows;  // cell rows of the band evaluated by this launch
     int top_row;       // 1: this launch evaluates only dxq[ny][:] (exact j = ny lattice row) into band row out_row
     long out_row;
+    long faithful_from;  // lattice rows (unique index (N-1)*cell + node) >= this use bp_point, the others bp_point_fast
     double* dxq;
     double* dyq;
     double* daq;
@@ -226,11 +255,20 @@ __global__ __launch_bounds__(QT_THREADS) void bipolar_quad_kernel(QuadParams p) 
 
     // phase 1: per-point remainder, scaled to per-index arc lengths (OGG:131-132)
     const int npts = nr * nc;
+    // A lattice row keeps the literal sequence iff its absolute index is >= faithful_from (a function of the row alone,
+    // so the result of a cell does not depend on how the cap is cut into tiles or bands).
+    const long gu0 = (long)M * cj0;
+    const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
     for (int pt = tid; pt < npts; pt += QT_THREADS) {
         const int lr = pt / nc;
         const int lc = pt - lr * nc;
-        double phis, h_i, h_j, rden;
-        bp_point(s_row[lr], s_col[lc], p.rp, phis, h_i, h_j, rden);
+        double h_i, h_j;
+        if (p.top_row || gu0 + lr >= p.faithful_from) {
+            double phis, rden;
+            bp_point(s_row[lr], s_col[lc], p.rp, phis, h_i, h_j, rden);
+        } else {
+            bp_point_fast(s_row[lr], s_col[lc], rp2x4, rp2, h_i, h_j);
+        }
         s_dx[lr * NC + lc] = h_i * 2 * kPi / (double)p.nx;
         s_dy[lr * NC + lc] = h_j * (90 - p.lat0_bp) * kPi180 / (double)p.ny;
     }
@@ -380,7 +418,14 @@ int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp
                     (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
                 OGG_ESHAPE, "ogg_bipolar_cap_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0, n_cell_rows,
                 n_dx_rows, ny);
-    QuadParams p{nx, ny, lat0_bp, lon_bp, rp, Re, j0, n_cell_rows, 0, 0, dxq, dyq, daq, make_nodes(order)};
+    // OGG_BP_ALG_GAP_DEG: distance from the pole (degrees of cap latitude) below which the literal operation sequence of
+    // the reference is kept; "inf" keeps it everywhere.  Default 2.0 (see bp_point_fast).
+    double gap = 2.0;
+    if (const char* e = getenv("OGG_BP_ALG_GAP_DEG")) gap = atof(e);
+    long jf = (long)ceil((double)ny * (1.0 - gap / (90.0 - lat0_bp)));  // first cell row inside the gap
+    if (!(jf > 0)) jf = 0;                                               // also catches gap = inf / NaN
+    if (jf > ny) jf = ny;
+    QuadParams p{nx, ny, lat0_bp, lon_bp, rp, Re, j0, n_cell_rows, 0, 0, (long)(order - 1) * jf, dxq, dyq, daq, make_nodes(order)};
     hipStream_t s = ogg::as_stream(stream);
     switch (order) {
         case 2: return launch_quad<2>(p, n_dx_rows, s);
