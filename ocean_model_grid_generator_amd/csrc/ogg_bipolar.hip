@@ -3,12 +3,12 @@
 //   bipolar_cap_metrics_quad_fast      OGG:136-188  (+ bipolar_cap_ij_array OGG:125-133, quadrature OGG:191-255)
 //
 // K4 is fp64-VALU bound (an acos, a tan, an atan, a cos and two sqrt per lattice point; 24 B written per cell).
-// One workgroup owns a tile of QT_ROWS x QT_COLS cells.  Lobatto nodes on shared cell edges are bit-identical
-// in the reference (node n-1 of cell k == node 0 of cell k+1 == k+1 exactly), so the tile evaluates each
-// unique lattice point once -- (n-1)^2 instead of n^2 evaluations per cell -- into LDS, after splitting the
-// projection into its row-only part (5 libm calls per lattice row), its column-only part (sincos + fmod per
-// lattice column) and the per-point remainder.  Each thread then reduces one cell from LDS in the reference's
-// summation order (OGG:216-221, 246-253).  The full lattice (138 M points at 1/8 degree) is never materialised.
+// The projection is split into its row-only part (5 libm calls per lattice row), its column-only part (sincos + fmod
+// per lattice column) -- both tabulated once per call -- and the per-point remainder.  Lobatto nodes on shared cell
+// edges are bit-identical in the reference (node n-1 of cell k == node 0 of cell k+1 == k+1 exactly), so a wave that walks
+// a strip of cells evaluates every unique lattice point once -- (n-1)^2 instead of n^2 evaluations per cell -- and
+// exchanges edge values by wave shuffles; sums follow the reference's order (OGG:216-221, 246-253).  The full lattice
+// (138 M points at 1/8 degree) is never materialised.
 #include <cstdlib>
 
 #include "ogg_common.h"
@@ -82,26 +82,27 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
 //   tan(acos(A)/2)^2 = (1-A)/(1+A),   1 + (rp t)^2 = D/(1+A),  D = (1+A) + rp^2 (1-A)
 //   M_inv = rp (1+t^2) / (1+(rp t)^2) = 2 rp / D
 //   cos^2(phis PI/180) = sin^2(2 atan(rp t)) = 4 rp^2 (1-A)(1+A) / D^2
-// so the acos -> tan -> atan -> cos round trip of OGG:69-79 collapses to one division.  The identities are exact; the
+// so the acos -> tan -> atan -> cos round trip of OGG:69-79 collapses to one division (returns the SQUARES of h_i_inv and
+// of h_j_inv*N; the caller takes the roots and applies the per-index scale factors of OGG:131-132 as multiplications).  The identities are exact; the
 // results differ from the literal sequence only by rounding: <= 1e-14 relative where the cap latitude is >= 1.4 degrees
 // from the pole (measured against the oracle on the 1/8 degree lattice; 4e-15 at >= 4 degrees).  Nearer the pole the
 // LITERAL sequence loses digits (phis = 90 - small is rounded to 1 ulp of 90 before the cosine), and parity with the
 // reference means reproducing that, so lattice rows within OGG_BP_ALG_GAP_DEG (default 2) of the pole keep bp_point.
-OGG_DEV void bp_point_fast(const BpRow& r, const BpCol& c, double rp2x4, double rp2, double& h_i_inv, double& h_j_inv) {
+OGG_DEV void bp_point_fast(const BpRow& r, const BpCol& c, double rp2x4, double rp2, double& hi2, double& hj2) {
     const double a = c.alpha2, b = r.beta2_inv;
     const double a1 = 1 - a, b1 = 1 + b;
-    const double rden = 1.0 / (1.0 + a * b);
     const double A = c.sinla * r.sphig;
     const double p1 = 1 + A, m1 = 1 - A;
-    const double E = 1.0 / (p1 + rp2 * m1);
+    const double P = 1.0 + a * b;                 // 1/rden
+    const double D = p1 + rp2 * m1;
+    const double inv = 1.0 / (P * D);             // one division for both reciprocals
+    const double rden = D * inv, E = P * inv;
     const double MM = rp2x4 * (E * E);            // M_inv^2
     const double cc = MM * (m1 * p1);             // cos^2(phis)
     const double rr = rden * rden;
-    double hj = cc * a * a1 * b * b1 * rr + MM * a1 * rden;
-    double hi = cc * b1 * rr + MM * a * b * rden;
-    if (fabs(b) > kHuge) hj = hi = MM;
-    h_j_inv = sqrt(hj) * r.N_inv;
-    h_i_inv = sqrt(hi);
+    hj2 = cc * a * a1 * b * b1 * rr + MM * a1 * rden;
+    hi2 = cc * b1 * rr + MM * a * b * rden;
+    if (fabs(b) > kHuge) hj2 = hi2 = MM;
 }
 
 // lams of OGG:50-64
@@ -161,23 +162,47 @@ __global__ __launch_bounds__(MESH_TX) void bipolar_mesh_kernel(long Ni, long Nj,
 }
 
 // ---- quadrature metrics -------------------------------------------------------------------------------------
-constexpr int QT_ROWS = 4;    // cell rows per workgroup
-constexpr int QT_COLS = 64;   // cell columns per workgroup
-constexpr int QT_THREADS = QT_ROWS * QT_COLS;
-
 struct QuadParams {
     long nx, ny;
     double lat0_bp, lon_bp, rp, Re;
-    long j0;           // first cell row of the band
-    long n_cell_rows;  // cell rows of the band evaluated by this launch
+    long j0;           // first cell row of the band (band-local output row 0)
+    long row_begin;    // cell rows [row_begin, row_end) are evaluated by this launch
+    long row_end;
     int top_row;       // 1: this launch evaluates only dxq[ny][:] (exact j = ny lattice row) into band row out_row
     long out_row;
-    long faithful_from;  // lattice rows (unique index (N-1)*cell + node) >= this use bp_point, the others bp_point_fast
+    long rows_per_chunk;  // cell rows one wave walks (its first lattice row is recomputed: 1/((N-1)*rows_per_chunk) extra)
+    const BpRow* row_tab;  // [(N-1)*ny + 2]: unique lattice rows; entry (N-1)*ny is the ny-0.001 row, the last one is j = ny exactly
+    const BpCol* col_tab;  // [(N-1)*nx + 1]: unique lattice columns
     double* dxq;
     double* dyq;
     double* daq;
     QuadNodes q;
 };
+
+// row-only and column-only parts of the projection for every unique lattice row / column of the cap (OGG:126-127,
+// 41-46, 75-78), evaluated once per call instead of once per tile
+template <int N>
+__global__ void bipolar_tables_kernel(QuadParams p, BpRow* row_tab, BpCol* col_tab) {
+    constexpr int M = N - 1;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
+    if (k < n_rows) {
+        double jv;
+        if (k == M * p.ny)
+            jv = (double)p.ny - 0.001;  // OGG:146-147: last node of cell ny-1
+        else if (k == M * p.ny + 1)
+            jv = lattice_node(p.q, 0, p.ny);  // first node of cell ny: j = ny exactly (feeds dxq[ny])
+        else
+            jv = lattice_node(p.q, (int)(k % M), k / M);
+        const double latg = p.lat0_bp + (jv * (90 - p.lat0_bp)) / (double)p.ny;   // OGG:127
+        row_tab[k] = bp_row(latg, p.rp);
+    } else if (k < n_rows + n_cols) {
+        const long u = k - n_rows;
+        const double iv = lattice_node(p.q, (int)(u % M), u / M);
+        const double lon = p.lon_bp + (iv * 360.0) / (double)p.nx;               // OGG:126
+        col_tab[u] = bp_col(lon, p.lon_bp);
+    }
+}
 
 template <int N>
 OGG_DEV double quad_average_1d(const double* y) {  // OGG:207-222
@@ -187,129 +212,141 @@ OGG_DEV double quad_average_1d(const double* y) {  // OGG:207-222
     return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
 }
 
-template <int N, typename F>
-OGG_DEV double quad_average_2d(F y) {  // y(jj, ii); OGG:225-255
-    if (N == 2) {
-        const double d = 1.0 / 2.0;
-        return d * d * (y(0, 0) + y(0, 1) + y(1, 0) + y(1, 1));
-    }
-    if (N == 3) {
-        const double d = 1.0 / 6.0;
-        return d * d * (y(0, 0) + y(0, 2) + y(2, 0) + y(2, 2) + 4.0 * (y(0, 1) + y(1, 0) + y(1, 2) + y(2, 1) + 4.0 * y(1, 1)));
-    }
-    const double w4[4] = {1.0, 5.0, 5.0, 1.0};
-    const double w5[5] = {9.0, 49.0, 64.0, 49.0, 9.0};
-    const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
-    double ysum = 0.0;
-#pragma unroll
-    for (int jj = 0; jj < N; ++jj) {
-#pragma unroll
-        for (int ii = 0; ii < N; ++ii) {
-            const double w = (N == 4) ? (w4[ii] * w4[jj]) : (w5[ii] * w5[jj]);
-            ysum = ysum + w * y(jj, ii);
-        }
-    }
-    return d * d * ysum;
+template <int N>
+OGG_DEV double quad_weight_1d(int k) {  // w[k] of OGG:240 / 248, as selects (k may be a run-time value)
+    if (N == 4) return (k == 0 || k == 3) ? 1.0 : 5.0;
+    return (k == 0 || k == 4) ? 9.0 : ((k == 2) ? 64.0 : 49.0);
 }
 
-template <int N>
-__global__ __launch_bounds__(QT_THREADS) void bipolar_quad_kernel(QuadParams p) {
-    constexpr int M = N - 1;               // unique nodes per cell and direction
-    constexpr int NR = M * QT_ROWS + 1;    // lattice rows of the tile
-    constexpr int NC = M * QT_COLS + 1;    // lattice columns of the tile
-    __shared__ double s_dx[NR * NC];
-    __shared__ double s_dy[NR * NC];
-    __shared__ BpRow s_row[NR];
-    __shared__ BpCol s_col[NC];
+// A wave owns a vertical strip of 63 cells (lane 63 is a halo lane: the first cell of the next strip) and walks up the
+// cell rows of its chunk.  Each lane evaluates the (N-1) x (N-1) lattice points of its cell that are not on the cell's
+// right or top edge; the right-edge values are the left-edge values of lane+1 (one wave shuffle), the top-edge row is the
+// bottom row of the next cell row and is evaluated once and reused.  So every unique lattice point of the strip is
+// evaluated exactly once -- (N-1)^2 instead of N^2 evaluations per cell -- with no LDS and no barrier; the row-only
+// factors are wave-uniform (scalar loads), the column-only factors stay in registers for the whole walk.  Sums are taken
+// in the reference's order (OGG:216-221, 244-253).
+constexpr int QS_CELLS = 63;   // cells per wave strip
+constexpr int QS_WAVES = 4;    // strips per workgroup
 
-    const int tid = threadIdx.x;
-    const long ci0 = (long)blockIdx.x * QT_COLS;                          // first cell column of the tile
-    const long cj0 = p.top_row ? p.ny : p.j0 + (long)blockIdx.y * QT_ROWS;  // first cell row of the tile
-    const long cj_end = p.top_row ? p.ny + 1 : p.j0 + p.n_cell_rows;     // one past the last cell row wanted
-    const int nrows_cells = (int)((cj_end - cj0 < QT_ROWS) ? (cj_end - cj0) : QT_ROWS);
-    const int ncols_cells = (int)((p.nx - ci0 < QT_COLS) ? (p.nx - ci0) : QT_COLS);
-    const int nr = p.top_row ? 1 : M * nrows_cells + 1;  // lattice rows needed
-    const int nc = M * ncols_cells + 1;                  // lattice columns needed
+template <int N, bool FAITHFUL>
+struct RowEval {
+    double dx[N];  // dx at this lane's columns ii = 0..N-2 and, in [N-1], at the right edge (from lane+1)
+    double dy[N];
+};
 
-    // phase 0: row-only and column-only parts of the projection
-    for (int l = tid; l < nr + nc; l += QT_THREADS) {
-        if (l < nr) {
-            const long cell = cj0 + l / M;
-            const int node = l % M;
-            double jv = lattice_node(p.q, node, cell);
-            // OGG:146-147: the last node of cell ny-1 (== ny) is moved to ny-0.001; the first node of cell ny
-            // (also == ny, used for dxq[ny]) is not.
-            if (!p.top_row && cell == p.ny && node == 0) jv = (double)p.ny - 0.001;
-            const double latg = p.lat0_bp + (jv * (90 - p.lat0_bp)) / (double)p.ny;   // OGG:127
-            s_row[l] = bp_row(latg, p.rp);
-        } else {
-            const int lc = l - nr;
-            const long cell = ci0 + lc / M;
-            const int node = lc % M;
-            const double iv = lattice_node(p.q, node, cell);
-            const double lon = p.lon_bp + (iv * 360.0) / (double)p.nx;               // OGG:126
-            s_col[lc] = bp_col(lon, p.lon_bp);
-        }
-    }
-    __syncthreads();
-
-    // phase 1: per-point remainder, scaled to per-index arc lengths (OGG:131-132)
-    const int npts = nr * nc;
-    // A lattice row keeps the literal sequence iff its absolute index is >= faithful_from (a function of the row alone,
-    // so the result of a cell does not depend on how the cap is cut into tiles or bands).
-    const long gu0 = (long)M * cj0;
-    const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
-    for (int pt = tid; pt < npts; pt += QT_THREADS) {
-        const int lr = pt / nc;
-        const int lc = pt - lr * nc;
-        double h_i, h_j;
-        if (p.top_row || gu0 + lr >= p.faithful_from) {
-            double phis, rden;
-            bp_point(s_row[lr], s_col[lc], p.rp, phis, h_i, h_j, rden);
-        } else {
-            bp_point_fast(s_row[lr], s_col[lc], rp2x4, rp2, h_i, h_j);
-        }
-        s_dx[lr * NC + lc] = h_i * 2 * kPi / (double)p.nx;
-        s_dy[lr * NC + lc] = h_j * (90 - p.lat0_bp) * kPi180 / (double)p.ny;
-    }
-    __syncthreads();
-
-    // phase 2: one thread per cell, reference summation order
-    const int cr = tid / QT_COLS;
-    const int cc = tid % QT_COLS;
-    if (cc >= ncols_cells) return;
-    const long ci = ci0 + cc;
-    if (p.top_row) {
-        if (cr != 0) return;
-        double yv[N];
+template <int N, bool FAITHFUL>
+OGG_DEV void eval_lattice_row(const QuadParams& p, long u, const BpCol* col, double sx, double sy, double rp2x4, double rp2,
+                              RowEval<N, FAITHFUL>& o) {
+    constexpr int M = N - 1;
+    const BpRow r = p.row_tab[u];  // wave-uniform
+    if (FAITHFUL) {
+        // one point at a time (the libm calls of several points interleaved cost 225 VGPRs = 2 waves/SIMD); the column
+        // entry and the result slot are picked with compare-selects so that no register array is indexed dynamically
+#pragma unroll 1
+        for (int ii = 0; ii < M; ++ii) {
+            BpCol c = col[0];
 #pragma unroll
-        for (int ii = 0; ii < N; ++ii) yv[ii] = s_dx[M * cc + ii];
-        p.dxq[p.out_row * p.nx + ci] = quad_average_1d<N>(yv) * p.Re;
+            for (int k = 1; k < M; ++k) {
+                c.sinla = (ii == k) ? col[k].sinla : c.sinla;
+                c.alpha2 = (ii == k) ? col[k].alpha2 : c.alpha2;
+            }
+            double phis, rden, h_i, h_j;
+            bp_point(r, c, p.rp, phis, h_i, h_j, rden);
+            const double dx = h_i * 2 * kPi / (double)p.nx;                        // OGG:131
+            const double dy = h_j * (90 - p.lat0_bp) * kPi180 / (double)p.ny;      // OGG:132
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                o.dx[k] = (ii == k) ? dx : o.dx[k];
+                o.dy[k] = (ii == k) ? dy : o.dy[k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < M; ++ii) {
+            double hi2, hj2;
+            bp_point_fast(r, col[ii], rp2x4, rp2, hi2, hj2);
+            o.dx[ii] = sqrt(hi2) * sx;
+            o.dy[ii] = sqrt(hj2) * (r.N_inv * sy);
+        }
+    }
+    o.dx[M] = __shfl_down(o.dx[0], 1);
+    o.dy[M] = __shfl_down(o.dy[0], 1);
+}
+
+template <int N, bool FAITHFUL>
+__global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams p) {
+    constexpr int M = N - 1;
+    const int lane = threadIdx.x & 63;
+    const long strip = (long)blockIdx.x * QS_WAVES + (threadIdx.x >> 6);
+    if (strip * QS_CELLS >= p.nx) return;  // wave-uniform
+    const long ci = strip * QS_CELLS + lane;
+    const long n_cols_tab = M * p.nx + 1;
+    BpCol col[M];
+#pragma unroll
+    for (int ii = 0; ii < M; ++ii) {
+        long u = M * ci + ii;
+        if (u > n_cols_tab - 1) u = n_cols_tab - 1;
+        col[ii] = p.col_tab[u];
+    }
+    const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
+    const double sx = (2 * kPi) / (double)p.nx, sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
+    const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
+    RowEval<N, FAITHFUL> cur;
+    if (p.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
+        eval_lattice_row<N, FAITHFUL>(p, (long)M * p.ny + 1, col, sx, sy, rp2x4, rp2, cur);
+        if (cell_lane) p.dxq[p.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
         return;
     }
-    if (cr >= nrows_cells) return;
-    const long out_r = cj0 + cr - p.j0;  // band-local output row
-    const int r0 = M * cr, c0 = M * cc;
-    {
-        double yv[N];
+    const long r0 = p.row_begin + (long)blockIdx.y * p.rows_per_chunk;
+    const long r1 = (r0 + p.rows_per_chunk < p.row_end) ? r0 + p.rows_per_chunk : p.row_end;
+    eval_lattice_row<N, FAITHFUL>(p, (long)M * r0, col, sx, sy, rp2x4, rp2, cur);
+    for (long c = r0; c < r1; ++c) {
+        const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
+        double dyc[N];                                                      // dy down this lane's left edge
+        double y2[(N <= 3) ? N * N : 1];
+        double ysum = 0.0;
 #pragma unroll
-        for (int ii = 0; ii < N; ++ii) yv[ii] = s_dx[r0 * NC + c0 + ii];
-        p.dxq[out_r * p.nx + ci] = quad_average_1d<N>(yv) * p.Re;                     // OGG:183,186
+        for (int k = 0; k < N; ++k) dyc[k] = 0.0;
+#pragma unroll(N <= 3 ? N : 1)
+        for (int jj = 0; jj < N; ++jj) {
+            if (jj > 0) eval_lattice_row<N, FAITHFUL>(p, (long)M * c + jj, col, sx, sy, rp2x4, rp2, cur);
+            const double wj = quad_weight_1d<N>(jj);
 #pragma unroll
-        for (int jj = 0; jj < N; ++jj) yv[jj] = s_dy[(r0 + jj) * NC + c0];
-        p.dyq[out_r * (p.nx + 1) + ci] = quad_average_1d<N>(yv) * p.Re;               // OGG:184,187
-        if (ci == p.nx - 1) {  // column nx: first node column of the cell beyond the grid == right edge of this cell
+            for (int ii = 0; ii < N; ++ii) {
+                const double pr = cur.dx[ii] * cur.dy[ii];                  // OGG:178
+                if (N <= 3) {
 #pragma unroll
-            for (int jj = 0; jj < N; ++jj) yv[jj] = s_dy[(r0 + jj) * NC + c0 + M];
-            p.dyq[out_r * (p.nx + 1) + p.nx] = quad_average_1d<N>(yv) * p.Re;
+                    for (int k = 0; k < N * N; ++k)
+                        if (N <= 3 && k == jj * N + ii) y2[(N <= 3) ? k : 0] = pr;
+                } else {
+                    ysum = ysum + (quad_weight_1d<N>(ii) * wj) * pr;        // OGG:244 / 252
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) dyc[k] = (jj == k) ? cur.dy[0] : dyc[k];
+        }
+        // cur now holds lattice row (c, N-1) == (c+1, 0): the bottom row of the next cell row
+        const long out_r = c - p.j0;
+        if (ci == p.nx) p.dyq[out_r * (p.nx + 1) + p.nx] = quad_average_1d<N>(dyc) * p.Re;  // first node column of cell nx
+        if (cell_lane) {
+            p.dxq[out_r * p.nx + ci] = dxq;
+            p.dyq[out_r * (p.nx + 1) + ci] = quad_average_1d<N>(dyc) * p.Re;                  // OGG:184,187
+            double da;
+            if (N == 2) {
+                const double d = 1.0 / 2.0;
+                da = d * d * (y2[0] + y2[1] + y2[(N <= 3) ? N : 0] + y2[(N <= 3) ? N + 1 : 0]);
+            } else if (N == 3) {
+                const double d = 1.0 / 6.0;
+                auto Y = [&](int a, int b) { return y2[(N == 3) ? a * 3 + b : 0]; };
+                da = d * d * (Y(0, 0) + Y(0, 2) + Y(2, 0) + Y(2, 2) + 4.0 * (Y(0, 1) + Y(1, 0) + Y(1, 2) + Y(2, 1) + 4.0 * Y(1, 1)));
+            } else {
+                const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
+                da = d * d * ysum;
+            }
+            p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;                                      // OGG:185
         }
     }
-    const double da = quad_average_2d<N>([&](int jj, int ii) {
-        return s_dx[(r0 + jj) * NC + c0 + ii] * s_dy[(r0 + jj) * NC + c0 + ii];       // OGG:178
-    });
-    p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;                                       // OGG:185
 }
-
 
 // ---- bipolar_cap_ij_array (OGG:125-133) at arbitrary fractional indices ---------------------------------------
 __global__ void bipolar_ij_kernel(long n_i, const double* __restrict__ iv, long n_j, const double* __restrict__ jv, long Ni,
@@ -349,21 +386,58 @@ QuadNodes make_nodes(int order) {  // OGG:191-204, host IEEE double
 }
 
 template <int N>
-int launch_quad(const QuadParams& p0, long n_dx_rows, hipStream_t s) {
-    QuadParams p = p0;
-    if (p.n_cell_rows > 0) {
-        p.top_row = 0;
-        dim3 grid((unsigned)((p.nx + QT_COLS - 1) / QT_COLS), (unsigned)((p.n_cell_rows + QT_ROWS - 1) / QT_ROWS));
-        bipolar_quad_kernel<N><<<grid, QT_THREADS, 0, s>>>(p);
+int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double gap_deg, hipStream_t s) {
+    constexpr int M = N - 1;
+    // table workspace from the stream-ordered allocator: no host synchronisation, safe with concurrent streams
+    const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
+    void* ws = nullptr;
+    OGG_HIP_CHECK(hipMallocAsync(&ws, (size_t)n_rows * sizeof(BpRow) + (size_t)n_cols * sizeof(BpCol), s));
+    BpRow* row_tab = static_cast<BpRow*>(ws);
+    BpCol* col_tab = reinterpret_cast<BpCol*>(row_tab + n_rows);
+    p.row_tab = row_tab;
+    p.col_tab = col_tab;
+    bipolar_tables_kernel<N><<<(unsigned)((n_rows + n_cols + 255) / 256), 256, 0, s>>>(p, row_tab, col_tab);
+    OGG_LAUNCH_CHECK();
+    // Cell rows >= jf (within gap_deg degrees of cap latitude from the pole) keep the literal operation sequence, the
+    // others use the algebraic reduction (see bp_point_fast).  A function of the absolute cell row only.
+    // The top edge of the last "fast" cell row jf-1 is the lattice row j = jf: it must be at least gap_deg from the pole;
+    // the last cell row (whose top edge is the ny-0.001 row) is always literal.
+    long jf = (long)floor((double)p.ny * (1.0 - gap_deg / (90.0 - p.lat0_bp)));
+    if (!(jf > 0)) jf = 0;  // also catches gap = inf / NaN
+    if (jf > p.ny - 1) jf = p.ny - 1;
+    const long lo = p.j0, hi = p.j0 + n_cell_rows;
+    const long n_strips = (p.nx + QS_CELLS - 1) / QS_CELLS;
+    const unsigned gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);
+    // enough waves to fill 1024 SIMDs several times over, without recomputing more than ~1/(N-1) of the lattice rows
+    auto chunk_rows = [&](long rows, long target_waves) {
+        long rpc = (rows * n_strips + target_waves - 1) / target_waves;
+        return rpc < 1 ? 1L : (rpc > 32 ? 32L : rpc);
+    };
+    p.top_row = 0;
+    if (lo < hi && lo < jf) {
+        p.row_begin = lo;
+        p.row_end = hi < jf ? hi : jf;
+        p.rows_per_chunk = chunk_rows(p.row_end - p.row_begin, 8192);
+        dim3 grid(gx, (unsigned)((p.row_end - p.row_begin + p.rows_per_chunk - 1) / p.rows_per_chunk));
+        bipolar_quad_kernel<N, false><<<grid, 64 * QS_WAVES, 0, s>>>(p);
         OGG_LAUNCH_CHECK();
     }
-    if (n_dx_rows > p.n_cell_rows) {
+    if (lo < hi && hi > jf) {
+        p.row_begin = lo > jf ? lo : jf;
+        p.row_end = hi;
+        p.rows_per_chunk = chunk_rows(p.row_end - p.row_begin, 4096);
+        dim3 grid(gx, (unsigned)((p.row_end - p.row_begin + p.rows_per_chunk - 1) / p.rows_per_chunk));
+        bipolar_quad_kernel<N, true><<<grid, 64 * QS_WAVES, 0, s>>>(p);
+        OGG_LAUNCH_CHECK();
+    }
+    if (n_dx_rows > n_cell_rows) {
         p.top_row = 1;
-        p.out_row = p.n_cell_rows;
-        dim3 grid((unsigned)((p.nx + QT_COLS - 1) / QT_COLS), 1);
-        bipolar_quad_kernel<N><<<grid, QT_THREADS, 0, s>>>(p);
+        p.out_row = n_cell_rows;
+        dim3 grid(gx, 1);
+        bipolar_quad_kernel<N, true><<<grid, 64 * QS_WAVES, 0, s>>>(p);
         OGG_LAUNCH_CHECK();
     }
+    OGG_HIP_CHECK(hipFreeAsync(ws, s));
     return OGG_OK;
 }
 
@@ -422,16 +496,15 @@ int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp
     // the reference is kept; "inf" keeps it everywhere.  Default 2.0 (see bp_point_fast).
     double gap = 2.0;
     if (const char* e = getenv("OGG_BP_ALG_GAP_DEG")) gap = atof(e);
-    long jf = (long)ceil((double)ny * (1.0 - gap / (90.0 - lat0_bp)));  // first cell row inside the gap
-    if (!(jf > 0)) jf = 0;                                               // also catches gap = inf / NaN
-    if (jf > ny) jf = ny;
-    QuadParams p{nx, ny, lat0_bp, lon_bp, rp, Re, j0, n_cell_rows, 0, 0, (long)(order - 1) * jf, dxq, dyq, daq, make_nodes(order)};
+    QuadParams p{};
+    p.nx = nx, p.ny = ny, p.lat0_bp = lat0_bp, p.lon_bp = lon_bp, p.rp = rp, p.Re = Re, p.j0 = j0;
+    p.dxq = dxq, p.dyq = dyq, p.daq = daq, p.q = make_nodes(order);
     hipStream_t s = ogg::as_stream(stream);
     switch (order) {
-        case 2: return launch_quad<2>(p, n_dx_rows, s);
-        case 3: return launch_quad<3>(p, n_dx_rows, s);
-        case 4: return launch_quad<4>(p, n_dx_rows, s);
-        default: return launch_quad<5>(p, n_dx_rows, s);
+        case 2: return launch_quad<2>(p, n_dx_rows, n_cell_rows, gap, s);
+        case 3: return launch_quad<3>(p, n_dx_rows, n_cell_rows, gap, s);
+        case 4: return launch_quad<4>(p, n_dx_rows, n_cell_rows, gap, s);
+        default: return launch_quad<5>(p, n_dx_rows, n_cell_rows, gap, s);
     }
 }
 
