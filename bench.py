@@ -54,7 +54,7 @@ def band_points(plan, rank, world, sg_mod):
     ni1 = plan.Ni + 1
     pts = {}
     for s in plan.subs:
-        lo, hi = sg_mod.band(s.nj1, rank, world)
+        lo, hi = sg_mod.Supergrid.rows_of(s, rank, world)
         n = (hi - lo) * ni1
         if s.kind in ("mercator", "latlon"):
             pts.setdefault("latlon_fused", []).append(n)
@@ -138,6 +138,9 @@ def main():
                     help="fused: lat-lon sub-grids from their 1-D axes in one kernel (no reads, no halo); stencil: tile, RCCL halo, "
                          "generic 2x3-stencil kernel")
     ap.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline runs 1/div of the rows of every sub-grid (0: skip)")
+    ap.add_argument("--as-rank", type=int, default=None, help="experiment: run only the bands of this rank of --as-world on one GPU")
+    ap.add_argument("--as-world", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
     args = ap.parse_args()
 
     import torch
@@ -159,7 +162,10 @@ def main():
 
     flags = WORKLOADS[args.workload]
     plan = supergrid.SupergridPlan(**flags)
-    sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
+    if args.as_rank is not None:  # single-GPU rehearsal of one rank's share
+        sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device=device, halo="recompute", latlon=args.latlon)
+    else:
+        sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
 
     def sync():
         torch.cuda.synchronize()
@@ -169,19 +175,36 @@ def main():
 
     for _ in range(args.warmup):
         sg.step()
+    use_graph = bool(args.graph) and not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
+    if use_graph:
+        sg.capture()
+        sg.replay()  # one untimed replay
     sync()
-    sg._events = {}
+    # timed region: exactly K passes
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sg.phase_a()
-        sg.exchange_halo()
-        sg.phase_b()
+        if use_graph:
+            sg.replay()
+        else:
+            sg.phase_a()
+            sg.exchange_halo()
+            sg.phase_b()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
+    # stream (events cannot be read back from inside a replayed graph)
+    sg._events = {}
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        sg.phase_a()
+        sg.exchange_halo()
+        sg.phase_b()
+    torch.cuda.synchronize()
+    dt_eager = time.perf_counter() - t1
     ktimes = sg.kernel_times_ms()
 
     if rank == 0:
@@ -208,7 +231,8 @@ def main():
                        "flags": flags, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
                        "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
                            world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
-            "device": _lib.device_name(),
+            "device": _lib.device_name(), "launch": "hip graph replay" if use_graph else "eager",
+            "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["hbm_frac"], "traffic": traffic,

@@ -137,6 +137,13 @@ int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp
                                      double* daq, void* stream);
 int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
                                  double* dxq, double* dyq, double* daq);
+/* Same with a caller-provided device workspace for the row/column tables (at least ogg_bipolar_quad_workspace_bytes
+ * bytes): no allocation of any kind inside the call, so it can be captured into a HIP graph.  The plain _dev form takes
+ * the tables from the stream-ordered allocator (hipMallocAsync / hipFreeAsync). */
+long ogg_bipolar_quad_workspace_bytes(int order, long nx, long ny);
+int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                        long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
+                                        void* workspace, long workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Displaced-pole Southern cap

@@ -44,6 +44,8 @@ SIGNATURES = {
     "ogg_bipolar_cap_mesh": [c_long, c_long, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_bipolar_cap_metrics_quad_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_long,
                                          c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogg_bipolar_cap_metrics_quad_ws_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_long,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ogg_bipolar_cap_metrics_quad": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
                                      c_void_p],
     "ogg_displaced_pole_mesh_dev": [c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_double, c_double, c_double,
@@ -88,6 +90,7 @@ SIGNATURES = {
     "ogg_stream_synchronize": [c_void_p],
 }
 STRING_GETTERS = ("ogg_last_error", "ogg_version")
+LONG_GETTERS = {"ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long]}
 
 _lib = None
 
@@ -125,6 +128,9 @@ def load():
     for name in STRING_GETTERS:
         getattr(lib, name).restype = ctypes.c_char_p
         getattr(lib, name).argtypes = []
+    for name, argtypes in LONG_GETTERS.items():
+        getattr(lib, name).restype = c_long
+        getattr(lib, name).argtypes = argtypes
     _lib = lib
     return lib
 

@@ -386,12 +386,17 @@ QuadNodes make_nodes(int order) {  // OGG:191-204, host IEEE double
 }
 
 template <int N>
-int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double gap_deg, hipStream_t s) {
+int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double gap_deg, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
     constexpr int M = N - 1;
-    // table workspace from the stream-ordered allocator: no host synchronisation, safe with concurrent streams
+    // table workspace: the caller's (graph-capturable: no allocation at all), or from the stream-ordered allocator (no host
+    // synchronisation, safe with concurrent streams)
     const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
-    void* ws = nullptr;
-    OGG_HIP_CHECK(hipMallocAsync(&ws, (size_t)n_rows * sizeof(BpRow) + (size_t)n_cols * sizeof(BpCol), s));
+    const size_t need = (size_t)n_rows * sizeof(BpRow) + (size_t)n_cols * sizeof(BpCol);
+    void* ws = ext_ws;
+    if (ext_ws)
+        OGG_REQUIRE((size_t)ext_ws_bytes >= need, OGG_EARG, "bipolar quadrature workspace too small: %ld < %zu bytes", ext_ws_bytes, need);
+    else
+        OGG_HIP_CHECK(hipMallocAsync(&ws, need, s));
     BpRow* row_tab = static_cast<BpRow*>(ws);
     BpCol* col_tab = reinterpret_cast<BpCol*>(row_tab + n_rows);
     p.row_tab = row_tab;
@@ -437,7 +442,7 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double gap_deg, 
         bipolar_quad_kernel<N, true><<<grid, 64 * QS_WAVES, 0, s>>>(p);
         OGG_LAUNCH_CHECK();
     }
-    OGG_HIP_CHECK(hipFreeAsync(ws, s));
+    if (!ext_ws) OGG_HIP_CHECK(hipFreeAsync(ws, s));
     return OGG_OK;
 }
 
@@ -483,9 +488,14 @@ int ogg_bipolar_cap_ij_array_dev(long n_i, const double* i, long n_j, const doub
     return OGG_OK;
 }
 
-int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
-                                     long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
-                                     void* stream) {
+long ogg_bipolar_quad_workspace_bytes(int order, long nx, long ny) {
+    if (order < 2 || order > 5 || nx <= 0 || ny <= 0) return 0;
+    return (long)(((long)(order - 1) * ny + 2) * sizeof(BpRow) + ((long)(order - 1) * nx + 1) * sizeof(BpCol));
+}
+
+int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                        long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
+                                        void* workspace, long workspace_bytes, void* stream) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     OGG_REQUIRE(nx > 0 && ny > 0 && dxq && (n_cell_rows <= 0 || (dyq && daq)), OGG_EARG, "ogg_bipolar_cap_metrics_quad: bad argument");
     OGG_REQUIRE(j0 >= 0 && n_cell_rows >= 0 && j0 + n_cell_rows <= ny &&
@@ -501,11 +511,18 @@ int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp
     p.dxq = dxq, p.dyq = dyq, p.daq = daq, p.q = make_nodes(order);
     hipStream_t s = ogg::as_stream(stream);
     switch (order) {
-        case 2: return launch_quad<2>(p, n_dx_rows, n_cell_rows, gap, s);
-        case 3: return launch_quad<3>(p, n_dx_rows, n_cell_rows, gap, s);
-        case 4: return launch_quad<4>(p, n_dx_rows, n_cell_rows, gap, s);
-        default: return launch_quad<5>(p, n_dx_rows, n_cell_rows, gap, s);
+        case 2: return launch_quad<2>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
+        case 3: return launch_quad<3>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
+        case 4: return launch_quad<4>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
+        default: return launch_quad<5>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
     }
+}
+
+int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                     long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
+                                     void* stream) {
+    return ogg_bipolar_cap_metrics_quad_ws_dev(order, nx, ny, lat0_bp, lon_bp, rp, Re, j0, n_dx_rows, n_cell_rows, dxq, dyq, daq,
+                                               nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -19,10 +19,11 @@ namespace {
 using namespace ogg;
 
 constexpr int LF_TX = 256;
-constexpr int LF_ROWS = 32;
+constexpr int LF_ROWS = 32;  // maximum rows per workgroup (LDS row table); small bands use fewer so that the grid stays >= ~2000 workgroups
 
 struct FusedParams {
     long n_pt_rows, n_cell_rows, ni1;
+    int rows_per_block;
     const double* lat;  // lat[0 .. n_pt_rows-1] (+1 more entry when n_cell_rows == n_pt_rows)
     const double* lon;  // lon[0 .. ni1-1]
     double Re, Re2;
@@ -42,8 +43,8 @@ struct RowScalars {
 __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
     __shared__ RowScalars s_row[LF_ROWS + 1];
     const int tid = threadIdx.x;
-    const long js = (long)blockIdx.y * LF_ROWS;
-    const long je = (js + LF_ROWS < p.n_pt_rows) ? js + LF_ROWS : p.n_pt_rows;
+    const long js = (long)blockIdx.y * p.rows_per_block;
+    const long je = (js + p.rows_per_block < p.n_pt_rows) ? js + p.rows_per_block : p.n_pt_rows;
     const int nrows = (int)(je - js);
     // per-row scalars for rows js .. je (row je only when a cell row needs it)
     if (tid <= nrows) {
@@ -115,8 +116,11 @@ extern "C" int ogg_latlon_supergrid_dev(long n_pt_rows, long n_cell_rows, long n
     OGG_REQUIRE(lat1d && lon1d && x && y && angle, OGG_EARG, "ogg_latlon_supergrid: null pointer");
     OGG_REQUIRE(!metrics || (dx && (n_cell_rows == 0 || (dy && area))), OGG_EARG, "ogg_latlon_supergrid: null metrics output");
     if (n_pt_rows == 0) return OGG_OK;
-    FusedParams p{n_pt_rows, metrics ? n_cell_rows : 0, ni1, lat1d, lon1d, Re, pow(Re, 2.0), metrics, x, y, dx, dy, area, angle};
-    dim3 grid((unsigned)((ni1 + LF_TX - 1) / LF_TX), (unsigned)((n_pt_rows + LF_ROWS - 1) / LF_ROWS));
+    const long gx = (ni1 + LF_TX - 1) / LF_TX;
+    long rpb = (n_pt_rows * gx + 2047) / 2048;  // aim at >= 2048 workgroups (8 per CU)
+    rpb = rpb < 4 ? 4 : (rpb > LF_ROWS ? LF_ROWS : rpb);
+    FusedParams p{n_pt_rows, metrics ? n_cell_rows : 0, ni1, (int)rpb, lat1d, lon1d, Re, pow(Re, 2.0), metrics, x, y, dx, dy, area, angle};
+    dim3 grid((unsigned)gx, (unsigned)((n_pt_rows + rpb - 1) / rpb));
     latlon_fused_kernel<<<grid, LF_TX, 0, ogg::as_stream(stream)>>>(p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;

@@ -13,10 +13,11 @@ namespace {
 using namespace ogg;
 
 constexpr int MIDAS_TX = 256;   // columns per workgroup (4 waves)
-constexpr int MIDAS_ROWS = 16;  // point rows per workgroup
+constexpr int MIDAS_ROWS = 16;  // maximum point rows per workgroup; small bands use fewer (grid >= ~2000 workgroups)
 
 struct MidasParams {
     long nrows_xy, ni1, n_pt_rows, n_cell_rows;
+    int rows_per_block;
     const double* x;
     const double* y;
     double Re, Re2;
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(MIDAS_TX) void midas_angle_kernel(MidasParams p) {
     const long ni = ni1 - 1;
     const bool active = i < ni1;
     const bool has_r = i + 1 < ni1;
-    const long js = (long)blockIdx.y * MIDAS_ROWS;
-    const long je = (js + MIDAS_ROWS < p.n_pt_rows) ? js + MIDAS_ROWS : p.n_pt_rows;
+    const long js = (long)blockIdx.y * p.rows_per_block;
+    const long je = (js + p.rows_per_block < p.n_pt_rows) ? js + p.rows_per_block : p.n_pt_rows;
 
     RowVals cur = load_row(p.x, p.y, js, ni1, i, lane);
     RowQ q = {0.0, 0.0, 0.0, 0.0};
@@ -153,8 +154,11 @@ extern "C" int ogg_grid_metrics_midas_dev(long nrows_xy, long ni1, const double*
     if (n_pt_rows == 0) return OGG_OK;
     const bool metrics = dx || dy || area;
     if (!(dy || area)) n_cell_rows = 0;
-    MidasParams p{nrows_xy, ni1, n_pt_rows, n_cell_rows, x, y, Re, pow(Re, 2.0), dx, dy, area, angle};
-    dim3 grid((unsigned)((ni1 + MIDAS_TX - 1) / MIDAS_TX), (unsigned)((n_pt_rows + MIDAS_ROWS - 1) / MIDAS_ROWS));
+    const long gx = (ni1 + MIDAS_TX - 1) / MIDAS_TX;
+    long rpb = (n_pt_rows * gx + 2047) / 2048;  // aim at >= 2048 workgroups
+    rpb = rpb < (metrics ? 4 : 1) ? (metrics ? 4 : 1) : (rpb > MIDAS_ROWS ? MIDAS_ROWS : rpb);
+    MidasParams p{nrows_xy, ni1, n_pt_rows, n_cell_rows, (int)rpb, x, y, Re, pow(Re, 2.0), dx, dy, area, angle};
+    dim3 grid((unsigned)gx, (unsigned)((n_pt_rows + rpb - 1) / rpb));
     hipStream_t s = ogg::as_stream(stream);
     if (!metrics)
         midas_angle_kernel<false, true><<<grid, MIDAS_TX, 0, s>>>(p);

@@ -32,6 +32,22 @@ def band(n_rows, rank, world):
     return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
 
 
+def band_weighted(cost, rank, world):
+    """Contiguous rows [lo, hi) of `rank` such that every rank gets about the same total cost; `cost` is the per-row
+    cost array.  The boundaries are a function of (cost, world) only, identical on every rank."""
+    c = np.concatenate(([0.0], np.cumsum(np.asarray(cost, dtype=np.float64))))
+    total = c[-1]
+
+    def edge(r):
+        if r <= 0:
+            return 0
+        if r >= world:
+            return len(cost)
+        return int(np.searchsorted(c, total * r / world, side="left"))
+
+    return edge(rank), edge(rank + 1)
+
+
 class SubGridPlan(object):
     """Size and scalars of one sub-grid; `row0` is the first KEPT point row in the sub-grid's native numbering
     (e.g. the first row after the displaced-pole doughnut) and `nj1` the number of kept point rows."""
@@ -86,6 +102,14 @@ class SupergridPlan(object):
             Nj_ncap -= 1
         bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=lat0_bp, lon_bp=self.lon0,
                          rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
+        # Row cost for the band split: the quadrature kernel keeps the reference's literal operation sequence for the cell
+        # rows within OGG_BP_ALG_GAP_DEG (default 2) degrees of the pole (see bp_point_fast in csrc/ogg_bipolar.hip); such a
+        # row costs ~3.9x a row of the algebraic path (measured, mesh + quadrature + angle).
+        import os
+        gap = float(os.environ.get("OGG_BP_ALG_GAP_DEG", "2.0"))
+        jf = Nj_ncap * (1.0 - gap / (90.0 - lat0_bp))
+        jf = int(min(max(math.floor(jf) if jf == jf and jf > 0 else 0, 0), Nj_ncap - 1))
+        bp.row_cost = np.where(np.arange(Nj_ncap + 1) >= jf, 3.9, 1.0)
         # Southern Ocean (OGG:1080-1103)
         lat0_SO = -78.0
         lenlat_SO = latUp_SO - lat0_SO
@@ -162,7 +186,7 @@ class Supergrid(object):
         with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
             self.lon1d = torch.empty(ni1, dtype=torch.float64, device=self.device)
             for s in plan.subs:
-                lo, hi = band(s.nj1, rank, world)
+                lo, hi = self.rows_of(s, rank, world)
                 n = hi - lo
                 n_cell = min(hi, s.nj1 - 1) - lo  # cell rows owned (a cell row j belongs to the owner of point row j)
                 needs_halo = latlon == "stencil" and s.kind in ("mercator", "latlon") and n_cell > 0 and hi < s.nj1
@@ -175,7 +199,16 @@ class Supergrid(object):
                     b["axis"] = torch.empty(s.n_axis, dtype=torch.float64, device=self.device)
                 elif s.kind == "latlon":
                     b["axis"] = torch.empty(s.lnj + 1, dtype=torch.float64, device=self.device)
+                elif s.kind == "bipolar":
+                    b["ws_bytes"] = int(L.load().ogg_bipolar_quad_workspace_bytes(5, plan.Ni, s.Nj))
+                    b["ws"] = torch.empty(b["ws_bytes"], dtype=torch.uint8, device=self.device)
                 self.buf[s.name] = b
+
+    @staticmethod
+    def rows_of(s, rank, world):
+        """Point rows [lo, hi) of sub-grid `s` owned by `rank`: equal row counts, or equal cost where rows differ in cost."""
+        cost = getattr(s, "row_cost", None)
+        return band_weighted(cost, rank, world) if cost is not None else band(s.nj1, rank, world)
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -258,7 +291,7 @@ class Supergrid(object):
                 ops.append(dist.P2POp(dist.irecv, b["y"][b["n"]], self.rank + 1))
             # send my first row to the rank below if IT needs a halo: it does iff it owns cell rows and is not the top band
             if self.rank > 0 and b["n"] > 0:
-                lo_b, hi_b = band(s.nj1, self.rank - 1, self.world)
+                lo_b, hi_b = self.rows_of(s, self.rank - 1, self.world)
                 if min(hi_b, s.nj1 - 1) - lo_b > 0 and hi_b < s.nj1:
                     ops.append(dist.P2POp(dist.isend, b["x"][0], self.rank - 1))
                     ops.append(dist.P2POp(dist.isend, b["y"][0], self.rank - 1))
@@ -293,9 +326,10 @@ class Supergrid(object):
             else:
                 if not p.skip_metrics:
                     if s.kind == "bipolar":
-                        self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
+                        self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_ws_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
                                                                    s.rp, p.Re, b["lo"], b["n"], b["n_cell"], b["dx"].data_ptr(),
-                                                                   b["dy"].data_ptr(), b["area"].data_ptr(), st))
+                                                                   b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
+                                                                   b["ws_bytes"], st))
                     else:
                         j0 = s.row0 + b["lo"]
                         self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_dev", 4, p.Ni, s.Nj, p.lon0, s.lat0,
@@ -310,6 +344,26 @@ class Supergrid(object):
         self.phase_a()
         self.exchange_halo()
         self.phase_b()
+
+    def capture(self):
+        """Capture one pass (phases A and B) into a HIP graph; `replay()` then costs one graph launch instead of ~10 kernel
+        launches from Python.  Not available when the pass contains an RCCL halo exchange (stencil mode, world > 1)."""
+        torch = self.torch
+        if self.world > 1 and self.latlon == "stencil" and self.halo == "rccl":
+            raise RuntimeError("the RCCL halo exchange is not captured; use eager steps")
+        self._events = None
+        self.step()
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.phase_a()
+            self.exchange_halo()
+            self.phase_b()
+        self.graph = g
+        return g
+
+    def replay(self):
+        self.graph.replay()
 
     def kernel_times_ms(self):
         """Mean per-launch duration of each kernel over the events recorded since the last reset."""

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_table_covers_the_header():
     from ocean_model_grid_generator_amd import _lib
-    table = set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS)
+    table = set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS) | set(_lib.LONG_GETTERS)
     assert sorted(table) == declared_symbols()
     lib = _lib.load()
     assert lib.ogg_version().startswith(b"ogg_hip")

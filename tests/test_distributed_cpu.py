@@ -33,7 +33,7 @@ def _worker(rank, world, port, r, q):
     try:
         import ocean_model_grid_generator_amd.supergrid as sg_mod
         plan = _plan(sg_mod, r, ensure_nj_even=True)
-        g = sg_mod.Supergrid(plan, rank=rank, world=world, device="cpu", halo="rccl")
+        g = sg_mod.Supergrid(plan, rank=rank, world=world, device="cpu", halo="rccl", latlon="stencil")
         full = orc.make_supergrid(r, ensure_nj_even=True)["sub"]
         ok = True
         for s in plan.subs:
