@@ -42,7 +42,7 @@ ALG_BYTES = {
     "tile_latlon": ("point", 16),     # x, y written once
     "midas_angle": ("point", 48),     # x, y read (16 B) + dx, dy, area, angle_dx written (32 B)
     "angle_x": ("point", 24),         # x, y read + angle_dx written
-    "bipolar_mesh": ("point", 16),
+    "bipolar_mesh": ("point", 24),    # x, y, angle_dx written; no reads
     "bipolar_quad": ("point", 24),    # dx, dy, area written; no reads
     "dpole_mesh": ("point", 16),
     "dpole_quad": ("point", 24),
@@ -63,7 +63,6 @@ def band_points(plan, rank, world, sg_mod):
         elif s.kind == "bipolar":
             pts.setdefault("bipolar_mesh", []).append(n)
             pts.setdefault("bipolar_quad", []).append(n)
-            pts.setdefault("angle_x", []).append(n)
         else:
             pts.setdefault("dpole_mesh", []).append(n)
             pts.setdefault("dpole_quad", []).append(n)

@@ -119,6 +119,9 @@ int ogg_bipolar_projection_dev(long n, const double* lamg, const double* phig, d
  * (h_j_inv row Nj is computed but dropped by the reference; rows >= Nj are not written); either may be NULL. */
 int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
                              double* phis, double* h_i_inv, double* h_j_inv, void* stream);
+/* same, also writing angle_dx = angle_x(lams, phis) (nrows x (Ni+1); NULL to skip) without reading the mesh back */
+int ogg_bipolar_cap_mesh_angle_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
+                                   double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream);
 int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis,
                          double* h_i_inv, double* h_j_inv);
 

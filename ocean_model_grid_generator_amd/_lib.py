@@ -41,6 +41,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p],
     "ogg_bipolar_cap_mesh_dev": [c_long, c_long, c_double, c_double, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p],
+    "ogg_bipolar_cap_mesh_angle_dev": [c_long, c_long, c_double, c_double, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p],
     "ogg_bipolar_cap_mesh": [c_long, c_long, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_bipolar_cap_metrics_quad_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_long,
                                          c_void_p, c_void_p, c_void_p, c_void_p],

@@ -136,29 +136,71 @@ __global__ void bipolar_projection_kernel(long n, const double* __restrict__ lam
     if (hj) hj[k] = h_j;
 }
 
-// ---- mesh builder (OGG:103-122), rows j0 .. j0+nrows-1 ------------------------------------------------------
-constexpr int MESH_TX = 256;
+// ---- mesh builder (OGG:103-122) fused with angle_x (OGG:719-729), rows j0 .. j0+nrows-1 ------------------------
+// A wave owns 62 output columns plus one halo column on either side, so the i-1 / i+1 neighbours that angle_x needs
+// come from wave shuffles and every lane does the same work.  Row-only factors are computed once per row of the
+// workgroup (LDS), column-only factors once per lane.  For the coordinates, tan(acos(A)/2) is evaluated as
+// sqrt((1-A)/(1+A)) (exact identity; phis then differs from the literal sequence by at most 1 ulp of 90 degrees, 1.4e-14);
+// the scale factors, when requested, follow the literal sequence (bp_point).
+constexpr int MESH_WAVES = 4;
+constexpr int MESH_OUT = 62;   // output columns per wave
+constexpr int MESH_ROWS = 8;   // rows per workgroup
 
-__global__ __launch_bounds__(MESH_TX) void bipolar_mesh_kernel(long Ni, long Nj, double lat0_bp, double lon_bp, long j0,
-                                                               long nrows, double* __restrict__ lams,
-                                                               double* __restrict__ phis, double* __restrict__ hi,
-                                                               double* __restrict__ hj) {
-    const long i = (long)blockIdx.x * MESH_TX + threadIdx.x;
-    const long jl = blockIdx.y;
-    if (i > Ni || jl >= nrows) return;
-    const long j = j0 + jl;
+__global__ __launch_bounds__(64 * MESH_WAVES) void bipolar_mesh_kernel(long Ni, long Nj, double lat0_bp, double lon_bp, long j0,
+                                                                      long nrows, double* __restrict__ lams,
+                                                                      double* __restrict__ phis, double* __restrict__ hi,
+                                                                      double* __restrict__ hj, double* __restrict__ angle) {
+    __shared__ BpRow s_row[MESH_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long jl0 = (long)blockIdx.y * MESH_ROWS;
+    const int nr = (int)((nrows - jl0 < MESH_ROWS) ? (nrows - jl0) : MESH_ROWS);
     const double rp = tan(0.5 * (90 - lat0_bp) * kPi180);                              // OGG:117
+    if (tid < nr) {
+        const long j = j0 + jl0 + tid;
+        const double phig = lat0_bp + ((double)j * (90 - lat0_bp)) / (double)Nj;       // OGG:115
+        s_row[tid] = bp_row(phig, rp);
+    }
+    __syncthreads();
+    const long col0 = ((long)blockIdx.x * MESH_WAVES + wave) * MESH_OUT;  // first output column of this wave
+    if (col0 > Ni) return;                                                // wave-uniform
+    long i = col0 - 1 + lane;
+    i = i < 0 ? 0 : (i > Ni ? Ni : i);                                    // halo lanes beyond the row ends are clamped
+    const bool out = (lane >= 1) && (lane <= MESH_OUT) && (col0 - 1 + lane <= Ni);
     const double lamg = lon_bp + ((double)i * 360.0) / (double)Ni;                     // OGG:113
-    const double phig = lat0_bp + ((double)j * (90 - lat0_bp)) / (double)Nj;           // OGG:115
-    const BpRow r = bp_row(phig, rp);
     const BpCol c = bp_col(lamg, lon_bp);
-    double ps, h_i, h_j, rden;
-    bp_point(r, c, rp, ps, h_i, h_j, rden);
     const long ni1 = Ni + 1;
-    if (lams) lams[jl * ni1 + i] = bp_lams(r, c, rden, lamg, lon_bp);
-    if (phis) phis[jl * ni1 + i] = ps;
-    if (hi && i < Ni) hi[jl * Ni + i] = h_i * 2 * kPi / (double)Ni;                    // OGG:119
-    if (hj && j < Nj) hj[jl * ni1 + i] = h_j * kPi180 * (90 - lat0_bp) / (double)Nj;   // OGG:120
+    for (int r = 0; r < nr; ++r) {
+        const BpRow row = s_row[r];
+        const long jl = jl0 + r, j = j0 + jl;
+        const double rden = 1.0 / (1.0 + c.alpha2 * row.beta2_inv);                    // OGG:47
+        const double lam = bp_lams(row, c, rden, lamg, lon_bp);
+        const double A = c.sinla * row.sphig;
+        const double t = sqrt((1 - A) / (1 + A));                                      // == tan(acos(A)/2), OGG:69-70
+        const double phi = 90 - 2 * atan(rp * t) / kPi180;
+        if (out) {
+            lams[jl * ni1 + i] = lam;
+            phis[jl * ni1 + i] = phi;
+        }
+        if (hi || hj) {
+            double ps, h_i, h_j, rd;
+            bp_point(row, c, rp, ps, h_i, h_j, rd);
+            if (out && hi && i < Ni) hi[jl * Ni + i] = h_i * 2 * kPi / (double)Ni;                    // OGG:119
+            if (out && hj && j < Nj) hj[jl * ni1 + i] = h_j * kPi180 * (90 - lat0_bp) / (double)Nj;   // OGG:120
+        }
+        if (angle) {                                                                   // OGG:725-728
+            const double xl = __shfl_up(lam, 1), xr = __shfl_down(lam, 1);
+            const double yl = __shfl_up(phi, 1), yr = __shfl_down(phi, 1);
+            const double cy = cos(phi * kPi180);
+            double a;
+            if (i == 0)
+                a = atan2(yr - phi, (xr - lam) * cy);
+            else if (i == Ni)
+                a = atan2(phi - yl, (lam - xl) * cy);
+            else
+                a = atan2(yr - yl, (xr - xl) * cy);
+            if (out) angle[jl * ni1 + i] = a / kPi180;
+        }
+    }
 }
 
 // ---- quadrature metrics -------------------------------------------------------------------------------------
@@ -465,16 +507,23 @@ int ogg_bipolar_projection_dev(long n, const double* lamg, const double* phig, d
     return OGG_OK;
 }
 
-int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
-                             double* phis, double* h_i_inv, double* h_j_inv, void* stream) {
+int ogg_bipolar_cap_mesh_angle_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
+                                   double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream) {
     OGG_REQUIRE(Ni > 0 && Nj > 0 && j0 >= 0 && nrows >= 0 && j0 + nrows <= Nj + 1, OGG_ESHAPE,
                 "ogg_bipolar_cap_mesh: rows %ld..%ld outside 0..%ld", j0, j0 + nrows, Nj);
+    OGG_REQUIRE(lams && phis, OGG_EARG, "ogg_bipolar_cap_mesh: null output");
     if (nrows == 0) return OGG_OK;
-    dim3 grid((unsigned)((Ni + 1 + MESH_TX - 1) / MESH_TX), (unsigned)nrows);
-    bipolar_mesh_kernel<<<grid, MESH_TX, 0, ogg::as_stream(stream)>>>(Ni, Nj, lat0_bp, lon_bp, j0, nrows, lams, phis, h_i_inv,
-                                                                     h_j_inv);
+    const long n_waves = (Ni + 1 + MESH_OUT - 1) / MESH_OUT;
+    dim3 grid((unsigned)((n_waves + MESH_WAVES - 1) / MESH_WAVES), (unsigned)((nrows + MESH_ROWS - 1) / MESH_ROWS));
+    bipolar_mesh_kernel<<<grid, 64 * MESH_WAVES, 0, ogg::as_stream(stream)>>>(Ni, Nj, lat0_bp, lon_bp, j0, nrows, lams, phis, h_i_inv,
+                                                                             h_j_inv, angle_dx);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
+}
+
+int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
+                             double* phis, double* h_i_inv, double* h_j_inv, void* stream) {
+    return ogg_bipolar_cap_mesh_angle_dev(Ni, Nj, lat0_bp, lon_bp, j0, nrows, lams, phis, h_i_inv, h_j_inv, nullptr, stream);
 }
 
 int ogg_bipolar_cap_ij_array_dev(long n_i, const double* i, long n_j, const double* j, long Ni, long Nj, double lat0_bp,

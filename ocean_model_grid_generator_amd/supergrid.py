@@ -260,8 +260,8 @@ class Supergrid(object):
                 self._timed("tile_latlon", lambda: L.call("ogg_tile_latlon_dev", rows, ni1, self._p(b["axis"], s.row0 + b["lo"]),
                                                           self.lon1d.data_ptr(), b["x"].data_ptr(), b["y"].data_ptr(), st))
             elif s.kind == "bipolar":
-                self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
-                                                           b["x"].data_ptr(), b["y"].data_ptr(), None, None, st))
+                self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
+                                                           b["x"].data_ptr(), b["y"].data_ptr(), None, None, b["angle_dx"].data_ptr(), st))
             elif s.kind == "dpole":
                 self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
                                                          s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(), st))
@@ -335,8 +335,9 @@ class Supergrid(object):
                         self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_dev", 4, p.Ni, s.Nj, p.lon0, s.lat0,
                                                                  s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
                                                                  b["dy"].data_ptr(), b["area"].data_ptr(), st))
-                self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
-                                                      b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
+                if s.kind != "bipolar":  # the bipolar mesh kernel already wrote angle_dx
+                    self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
+                                                          b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
 
     def step(self, time_kernels=False):
         """One full pass of the hot path for this rank's bands; outputs stay in HBM."""
