@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline runs 1/div of the rows of every sub-grid (0: skip)")
     ap.add_argument("--as-rank", type=int, default=None, help="experiment: run only the bands of this rank of --as-world on one GPU")
     ap.add_argument("--as-world", type=int, default=1)
+    ap.add_argument("--overlap", type=int, default=1, help="run the caps on side streams next to the lat-lon sub-grids")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
     args = ap.parse_args()
 
@@ -166,6 +167,8 @@ def main():
     else:
         sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
 
+    sg.overlap = bool(args.overlap)
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -185,9 +188,7 @@ def main():
         if use_graph:
             sg.replay()
         else:
-            sg.phase_a()
-            sg.exchange_halo()
-            sg.phase_b()
+            sg.run_pass()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -197,11 +198,10 @@ def main():
     # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
     # stream (events cannot be read back from inside a replayed graph)
     sg._events = {}
+    sg.overlap = False  # kernels one after the other on one stream: undisturbed per-kernel durations
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        sg.phase_a()
-        sg.exchange_halo()
-        sg.phase_b()
+        sg.run_pass()
     torch.cuda.synchronize()
     dt_eager = time.perf_counter() - t1
     ktimes = sg.kernel_times_ms()

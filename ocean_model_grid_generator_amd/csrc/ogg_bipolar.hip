@@ -88,21 +88,23 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
 // from the pole (measured against the oracle on the 1/8 degree lattice; 4e-15 at >= 4 degrees).  Nearer the pole the
 // LITERAL sequence loses digits (phis = 90 - small is rounded to 1 ulp of 90 before the cosine), and parity with the
 // reference means reproducing that, so lattice rows within OGG_BP_ALG_GAP_DEG (default 2) of the pole keep bp_point.
-OGG_DEV void bp_point_fast(const BpRow& r, const BpCol& c, double rp2x4, double rp2, double& hi2, double& hj2) {
+OGG_DEV void bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
+                           double& hi2, double& hj2) {
+    // bb1 = b (1+b) is row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them
     const double a = c.alpha2, b = r.beta2_inv;
-    const double a1 = 1 - a, b1 = 1 + b;
+    const double ab = a * b;
     const double A = c.sinla * r.sphig;
     const double p1 = 1 + A, m1 = 1 - A;
-    const double P = 1.0 + a * b;                 // 1/rden
+    const double P = 1.0 + ab;                    // 1/rden
     const double D = p1 + rp2 * m1;
-    const double inv = 1.0 / (P * D);             // one division for both reciprocals
+    const double inv = rcp_nr(P * D);             // one reciprocal for both quotients
     const double rden = D * inv, E = P * inv;
     const double MM = rp2x4 * (E * E);            // M_inv^2
-    const double cc = MM * (m1 * p1);             // cos^2(phis)
-    const double rr = rden * rden;
-    hj2 = cc * a * a1 * b * b1 * rr + MM * a1 * rden;
-    hi2 = cc * b1 * rr + MM * a * b * rden;
-    if (fabs(b) > kHuge) hj2 = hi2 = MM;
+    const double ccrr = (MM * (m1 * p1)) * (rden * rden);   // cos^2(phis) rden^2
+    const double Mr = MM * rden;
+    hj2 = ccrr * (aa1 * bb1) + Mr * a1;
+    hi2 = ccrr * (1 + b) + Mr * ab;
+    // (the |beta2_inv| > HUGE case of OGG:86,94 only occurs on the exact j = ny row, which never takes this path)
 }
 
 // lams of OGG:50-64
@@ -303,12 +305,15 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, long u, const BpCol* col, dou
             }
         }
     } else {
+        const double bb1 = r.beta2_inv * (1 + r.beta2_inv), nsy = r.N_inv * sy;
 #pragma unroll
         for (int ii = 0; ii < M; ++ii) {
             double hi2, hj2;
-            bp_point_fast(r, col[ii], rp2x4, rp2, hi2, hj2);
-            o.dx[ii] = sqrt(hi2) * sx;
-            o.dy[ii] = sqrt(hj2) * (r.N_inv * sy);
+            const double a1 = 1 - col[ii].alpha2;
+            bp_point_fast(r, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, hi2, hj2);
+            o.dx[ii] = sqrt_nr(hi2) * sx;
+            // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): sqrt_nr(0) would be 0 * inf
+            o.dy[ii] = (hj2 > 0.0) ? sqrt_nr(hj2) * nsy : 0.0;
         }
     }
     o.dx[M] = __shfl_down(o.dx[0], 1);

@@ -68,6 +68,27 @@ OGG_DEV double cabs_np(cplx w) {
     return a * sqrt(fma(r, r, 1.0));
 }
 
+// 1/x and sqrt(x) for NORMAL, positive x from the hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) and two Newton steps
+// (<= 1 ulp): no denormal scaling, no fix-up.  Only used where a kernel documents that it departs from the reference's
+// literal operation sequence (ogg_bipolar.hip, bp_point_fast); everything else uses IEEE division and sqrt.
+OGG_DEV double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+OGG_DEV double sqrt_nr(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
 // Gauss-Lobatto node weights of OGG:191-204, computed on the host in IEEE double and passed by value.
 struct QuadNodes {
     double a[5];

@@ -104,12 +104,12 @@ class SupergridPlan(object):
                          rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
         # Row cost for the band split: the quadrature kernel keeps the reference's literal operation sequence for the cell
         # rows within OGG_BP_ALG_GAP_DEG (default 2) degrees of the pole (see bp_point_fast in csrc/ogg_bipolar.hip); such a
-        # row costs ~3.9x a row of the algebraic path (measured, mesh + quadrature + angle).
+        # row costs ~4.8x a row of the algebraic path (measured: mesh + quadrature, 2.03 vs 0.42 us per row at 1/8 degree).
         import os
         gap = float(os.environ.get("OGG_BP_ALG_GAP_DEG", "2.0"))
         jf = Nj_ncap * (1.0 - gap / (90.0 - lat0_bp))
         jf = int(min(max(math.floor(jf) if jf == jf and jf > 0 else 0, 0), Nj_ncap - 1))
-        bp.row_cost = np.where(np.arange(Nj_ncap + 1) >= jf, 3.9, 1.0)
+        bp.row_cost = np.where(np.arange(Nj_ncap + 1) >= jf, 4.8, 1.0)
         # Southern Ocean (OGG:1080-1103)
         lat0_SO = -78.0
         lenlat_SO = latUp_SO - lat0_SO
@@ -177,6 +177,8 @@ class Supergrid(object):
         self.plan, self.rank, self.world, self.halo, self.latlon = plan, rank, world, halo, latlon
         self.device = torch.device(device)
         self.peers = peers  # halo="local": list of all virtual ranks' Supergrid objects
+        self.overlap = True
+        self._side = None
         self.buf = {}
         self.timings = {}
         ni1 = plan.Ni + 1
@@ -235,14 +237,19 @@ class Supergrid(object):
     _events = None
 
     # -- phases ----------------------------------------------------------------------------------------------
-    def phase_a(self):
-        """Coordinates of this rank's bands."""
+    @staticmethod
+    def _selected(s, only, kinds):
+        return (only is None or s.name == only) and (kinds is None or s.kind in kinds)
+
+    def phase_a(self, only=None, kinds=None):
+        """Coordinates of this rank's bands (optionally of one sub-grid / of some kinds of sub-grid only)."""
         p, st = self.plan, self._stream()
         ni1 = p.Ni + 1
-        L.call("ogg_linear_axis_dev", ni1, p.lon0, p.lenlon, float(p.Ni), self.lon1d.data_ptr(), st)
+        if only is None:
+            L.call("ogg_linear_axis_dev", ni1, p.lon0, p.lenlon, float(p.Ni), self.lon1d.data_ptr(), st)
         for s in p.subs:
             b = self.buf[s.name]
-            if b["n"] == 0:
+            if b["n"] == 0 or not self._selected(s, only, kinds):
                 continue
             if s.kind in ("mercator", "latlon"):
                 if s.kind == "mercator":
@@ -299,13 +306,13 @@ class Supergrid(object):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
-    def phase_b(self):
+    def phase_b(self, only=None, kinds=None):
         """Metrics and angle of this rank's bands."""
         p, st = self.plan, self._stream()
         ni1 = p.Ni + 1
         for s in p.subs:
             b = self.buf[s.name]
-            if b["n"] == 0:
+            if b["n"] == 0 or not self._selected(s, only, kinds):
                 continue
             if p.skip_metrics:
                 for f in ("dx", "dy", "area"):
@@ -342,9 +349,38 @@ class Supergrid(object):
     def step(self, time_kernels=False):
         """One full pass of the hot path for this rank's bands; outputs stay in HBM."""
         self._events = {} if time_kernels else None
-        self.phase_a()
-        self.exchange_halo()
-        self.phase_b()
+        self.run_pass()
+
+    def run_pass(self):
+        """Phases A and B.  In fused mode the sub-grids are independent, so the caps run on two side streams next to the
+        lat-lon sub-grids (the HBM-bound lat-lon kernel overlaps the VALU-bound quadratures); everything joins back on
+        the caller's stream before returning.  Under graph capture this becomes a forked graph."""
+        torch = self.torch
+        if self.latlon != "fused" or self.device.type != "cuda" or not self.overlap:
+            self.phase_a()
+            self.exchange_halo()
+            self.phase_b()
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        caps = [s for s in self.plan.subs if s.kind in ("bipolar", "dpole")]
+        joins = []
+        for k, s in enumerate(caps):
+            st = self._side[k % 2]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                self.phase_a(only=s.name)
+                self.phase_b(only=s.name)
+                e = torch.cuda.Event()
+                e.record(st)
+                joins.append(e)
+        self.phase_a(kinds=("mercator", "latlon"))
+        self.phase_b(kinds=("mercator", "latlon"))
+        for e in joins:
+            main.wait_event(e)
 
     def capture(self):
         """Capture one pass (phases A and B) into a HIP graph; `replay()` then costs one graph launch instead of ~10 kernel
@@ -357,9 +393,7 @@ class Supergrid(object):
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.phase_a()
-            self.exchange_halo()
-            self.phase_b()
+            self.run_pass()
         self.graph = g
         return g
 
