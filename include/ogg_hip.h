@@ -192,6 +192,12 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                         double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
                                         double* dxq, double* dyq, double* daq, void* stream);
+/* Same with a caller-provided workspace for the lattice values of h_i, h_j (at least
+ * ogg_displaced_pole_quad_workspace_bytes(order, nx, n_cell_rows) bytes): no allocation inside the call. */
+long ogg_displaced_pole_quad_workspace_bytes(int order, long nx, long n_cell_rows);
+int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                           double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
+                                           double* dyq, double* daq, void* workspace, long workspace_bytes, void* stream);
 int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
                                     double Re, double* dxq, double* dyq, double* daq);
 

@@ -62,6 +62,8 @@ SIGNATURES = {
                                        c_double, c_double, c_int, c_void_p, c_void_p],
     "ogg_displaced_pole_metrics_quad_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_long,
                                             c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogg_displaced_pole_metrics_quad_ws_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_long,
+                                               c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ogg_displaced_pole_metrics_quad": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_void_p,
                                         c_void_p, c_void_p],
     "ogg_y_mercator": [c_long, c_long, c_void_p, c_void_p],
@@ -92,7 +94,8 @@ SIGNATURES = {
     "ogg_stream_synchronize": [c_void_p],
 }
 STRING_GETTERS = ("ogg_last_error", "ogg_version")
-LONG_GETTERS = {"ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long]}
+LONG_GETTERS = {"ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long],
+                "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long]}
 
 _lib = None
 

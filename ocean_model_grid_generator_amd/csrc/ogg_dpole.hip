@@ -386,6 +386,150 @@ __global__ __launch_bounds__(SW_TX) void dpole_sweep_kernel(SweepParams p) {
 }
 
 
+
+// ---- finite-difference scale factors on a lattice row (OGG:535-562), one workgroup per lattice row and probe group ----
+// JGROUP = false: h_i from the 2H probes (j, i +- m eps);  JGROUP = true: h_j from the probes (j +- m eps, i).
+// The two groups of a lattice row are independent scans, so they run as separate workgroups: twice the parallelism and
+// half the live registers of a kernel that carries all 4H probes.
+struct HParams {
+    long ni, nj;
+    double lon0, lat0, lam_pole, r_pole, eps;
+    long n_cols, n_rows;
+    const double* i_arr;  // explicit column indices, or NULL: Lobatto nodes of cells 0.. (lattice_M unique nodes per cell)
+    const double* j_arr;  // explicit row indices, or NULL: Lobatto nodes of cell rows row0_cell..
+    int lattice_M;
+    long row0_cell;
+    QuadNodes q;
+    double* h_i;          // [n_rows][n_cols] or NULL
+    double* h_j;
+};
+
+template <int F, bool JGROUP>
+__global__ __launch_bounds__(SW_TX) void dpole_h_kernel(HParams p) {
+    constexpr int H = F / 2;
+    __shared__ UnwrapShared<F> s_u;
+    __shared__ double s_carry_v[F];
+    __shared__ unsigned s_carry_state;
+    __shared__ double s_r[F + 1];
+    const int tid = threadIdx.x;
+    const long row = blockIdx.x;
+    double* out = JGROUP ? p.h_j : p.h_i;
+    SweepParams sp{};
+    sp.ni = p.ni, sp.nj = p.nj, sp.lon0 = p.lon0, sp.lat0 = p.lat0, sp.lam_pole = p.lam_pole, sp.r_pole = p.r_pole;
+    const DpConst c = dp_const(sp);
+    const double reps = 1.0 / p.eps;
+    const int M = p.lattice_M;
+    if (tid <= F) {  // s_r[0]: base row; s_r[2m-1]: j + m eps; s_r[2m]: j - m eps
+        double jv = p.j_arr ? p.j_arr[row] : lattice_node(p.q, (int)(row % M), p.row0_cell + row / M);
+        if (tid > 0) {
+            const double off = (double)((tid + 1) / 2) * p.eps;
+            jv = (tid & 1) ? jv + off : jv - off;
+        }
+        if (tid == 0 || JGROUP) s_r[tid] = dp_row_radius(jv, sp, c);
+    }
+    const double i_first = p.i_arr ? p.i_arr[0] : lattice_node(p.q, 0, 0);
+    __syncthreads();
+    for (long c0 = 0; c0 < p.n_cols; c0 += SW_TX) {
+        const long g = c0 + tid;
+        const bool active = g < p.n_cols;
+        double v[F], ph[F], seed[F];
+#pragma unroll
+        for (int q = 0; q < F; ++q) v[q] = ph[q] = seed[q] = 0.0;
+        if (active) {
+            const double iv = p.i_arr ? p.i_arr[g] : lattice_node(p.q, (int)(g % M), g / M);
+            if (JGROUP) {
+                const cplx ep = dp_column(iv, sp, c);
+#pragma unroll
+                for (int q = 0; q < F; ++q) dp_point(s_r[q + 1], ep, c, v[q], ph[q]);
+            } else {
+#pragma unroll
+                for (int m = 1; m <= H; ++m) {
+                    const double off = (double)m * p.eps;
+                    dp_point(s_r[0], dp_column(iv + off, sp, c), c, v[2 * (m - 1)], ph[2 * (m - 1)]);
+                    dp_point(s_r[0], dp_column(iv - off, sp, c), c, v[2 * (m - 1) + 1], ph[2 * (m - 1) + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < F; ++q) {  // seed lon_grid[0,0] of each probe's mesh (OGG:463)
+            double di = 0.0;
+            if (!JGROUP) {
+                const double off = (double)(q / 2 + 1) * p.eps;
+                di = (q & 1) ? -off : off;
+            }
+            seed[q] = p.lon0 + ((i_first + di) * 360.0) / (double)p.ni;
+        }
+        const unsigned st = unwrap_states<F>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
+        if (active && tid == SW_TX - 1) {
+#pragma unroll
+            for (int q = 0; q < F; ++q) s_carry_v[q] = v[q];
+            s_carry_state = st;
+        }
+        if (active) {
+            double ds[(H > 0) ? H : 1];
+#pragma unroll
+            for (int m = 0; m < H; ++m) {
+                const double x0 = ((st >> (2 * m)) & 1u) ? v[2 * m] - 360 : v[2 * m];              // OGG:473
+                const double x1 = ((st >> (2 * m + 1)) & 1u) ? v[2 * m + 1] - 360 : v[2 * m + 1];
+                ds[m] = great_arc(x0, ph[2 * m], x1, ph[2 * m + 1]);
+            }
+            out[row * p.n_cols + g] = central_difference<F>(ds, reps);
+        }
+    }
+}
+
+// ---- Lobatto quadrature of the lattice values, one thread per cell, reference summation order (OGG:585-599) --------
+struct ReduceParams {
+    long nx, n_cols;       // cells per row; lattice columns (M*nx + 1)
+    long n_cell_rows;      // cell rows of the band
+    long n_dx_rows;        // n_cell_rows, or n_cell_rows + 1 for the band that owns dxq[ny]
+    double Re;
+    const double* h_i;
+    const double* h_j;
+    double* dxq;
+    double* dyq;
+    double* daq;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void dpole_quad_reduce_kernel(ReduceParams p) {
+    constexpr int M = N - 1;
+    const long ci = (long)blockIdx.x * 256 + threadIdx.x;
+    const long cj = blockIdx.y;
+    if (ci >= p.nx) return;
+    const double* hi0 = p.h_i + (M * cj) * p.n_cols + M * ci;
+    double yv[N];
+#pragma unroll
+    for (int ii = 0; ii < N; ++ii) yv[ii] = hi0[ii];
+    p.dxq[cj * p.nx + ci] = qavg_1d<N>(yv) * p.Re;                              // OGG:594,598
+    if (cj >= p.n_cell_rows) return;                                          // the dxq[ny] row has no cells
+    const double* hj0 = p.h_j + (M * cj) * p.n_cols + M * ci;
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) yv[jj] = hj0[jj * p.n_cols];
+    p.dyq[cj * (p.nx + 1) + ci] = qavg_1d<N>(yv) * p.Re;                        // OGG:595,599
+    if (ci == p.nx - 1) {
+#pragma unroll
+        for (int jj = 0; jj < N; ++jj) yv[jj] = hj0[jj * p.n_cols + M];
+        p.dyq[cj * (p.nx + 1) + p.nx] = qavg_1d<N>(yv) * p.Re;
+    }
+    double da;
+    if (N == 2) {
+        const double d = 1.0 / 2.0;
+        da = d * d * (hi0[0] * hj0[0] + hi0[1] * hj0[1] + hi0[p.n_cols] * hj0[p.n_cols] + hi0[p.n_cols + 1] * hj0[p.n_cols + 1]);
+    } else {
+        const double w4[4] = {1.0, 5.0, 5.0, 1.0};
+        const double d = 1.0 / 12.0;
+        double ysum = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < N; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < N; ++ii)
+                ysum = ysum + w4[ii & 3] * w4[jj & 3] * (hi0[jj * p.n_cols + ii] * hj0[jj * p.n_cols + ii]);   // OGG:589,244
+        da = d * d * ysum;
+    }
+    p.daq[cj * p.nx + ci] = da * p.Re * p.Re;                                   // OGG:597
+}
+
 // ---- displacedPoleCap_projection on explicit 2-D lon/lat grids (OGG:447-467) and bare monotonic_bounding ---------
 struct DirectParams {
     long nj, ni;
@@ -503,20 +647,35 @@ int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, cons
     if (int e = check_cap(nx, ny)) return e;
     OGG_REQUIRE(fd_order == 2 || fd_order == 4 || fd_order == 6, OGG_EORDER, "order not coded");
     OGG_REQUIRE(n_i > 0 && n_j >= 0 && i && j && (h_i || h_j) && eps > 0, OGG_EARG, "ogg_displaced_pole_numerical_h: bad argument");
-    SweepParams p{};
-    p.ni = nx, p.nj = ny, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
-    p.eps = eps, p.Re = 1.0;
-    p.n_cols = n_i, p.n_rows = n_j, p.i_arr = i, p.j_arr = j;
-    p.out0 = h_i, p.out1 = h_j;
+    if (n_j == 0) return OGG_OK;
+    HParams p{};
+    p.ni = nx, p.nj = ny, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp, p.eps = eps;
+    p.n_cols = n_i, p.n_rows = n_j, p.i_arr = i, p.j_arr = j, p.lattice_M = 1;
+    p.h_i = h_i, p.h_j = h_j;
     hipStream_t s = ogg::as_stream(stream);
-    if (fd_order == 2) return launch_sweep<2, 1, MODE_EMIT>(p, n_j, s);
-    if (fd_order == 4) return launch_sweep<4, 1, MODE_EMIT>(p, n_j, s);
-    return launch_sweep<6, 1, MODE_EMIT>(p, n_j, s);
+#define OGG_LAUNCH_H(F)                                                                      \
+    do {                                                                                     \
+        if (h_i) dpole_h_kernel<F, false><<<(unsigned)n_j, SW_TX, 0, s>>>(p);                \
+        if (h_j) dpole_h_kernel<F, true><<<(unsigned)n_j, SW_TX, 0, s>>>(p);                 \
+    } while (0)
+    if (fd_order == 2)
+        OGG_LAUNCH_H(2);
+    else if (fd_order == 4)
+        OGG_LAUNCH_H(4);
+    else
+        OGG_LAUNCH_H(6);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
 }
 
-int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
-                                        double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
-                                        double* daq, void* stream) {
+long ogg_displaced_pole_quad_workspace_bytes(int order, long nx, long n_cell_rows) {
+    if (order < 2 || order > 5 || nx <= 0 || n_cell_rows < 0) return 0;
+    return 2L * ((long)(order - 1) * n_cell_rows + 1) * ((long)(order - 1) * nx + 1) * (long)sizeof(double);
+}
+
+int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                           double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
+                                           double* daq, void* workspace, long workspace_bytes, void* stream) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     // the quadrature order is forwarded as the finite-difference order (OGG:583-584): 3 and 5 are "not coded" there
     OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
@@ -526,25 +685,48 @@ int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0
                     (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
                 OGG_ESHAPE, "ogg_displaced_pole_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0,
                 n_cell_rows, n_dx_rows, ny);
-    SweepParams p{};
-    p.ni = nx, p.nj = ny, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
-    p.eps = 1e-3, p.Re = Re;  // OGG:583
-    p.nx = nx, p.ny = ny, p.j0 = j0;
-    p.n_cols = (long)(order - 1) * nx + 1;
-    p.n_rows = n_cell_rows;
-    p.q = ogg::quad_nodes_host(order);
-    p.out0 = dxq, p.out1 = dyq, p.out2 = daq;
+    if (n_dx_rows == 0) return OGG_OK;
+    const int M = order - 1;
     hipStream_t s = ogg::as_stream(stream);
-    int e;
-    p.top_row = 0;
-    e = (order == 2) ? launch_sweep<2, 2, MODE_QUAD>(p, n_cell_rows, s) : launch_sweep<4, 4, MODE_QUAD>(p, n_cell_rows, s);
-    if (e) return e;
-    if (n_dx_rows > n_cell_rows) {
-        p.top_row = 1;
-        p.out_row = n_cell_rows;
-        e = (order == 2) ? launch_sweep<2, 2, MODE_QUAD>(p, 1, s) : launch_sweep<4, 4, MODE_QUAD>(p, 1, s);
+    // lattice rows of the band: the unique Lobatto rows of its cell rows plus the closing row (which is dxq's row j0+n_cell_rows
+    // when the band owns it, and the top edge of the last cell row otherwise)
+    const long n_lat_rows = (long)M * n_cell_rows + 1, n_cols = (long)M * nx + 1;
+    const size_t need = 2 * (size_t)n_lat_rows * n_cols * sizeof(double);
+    void* ws = workspace;
+    if (workspace)
+        OGG_REQUIRE((size_t)workspace_bytes >= need, OGG_EARG, "displaced-pole quadrature workspace too small: %ld < %zu bytes", workspace_bytes, need);
+    else
+        OGG_HIP_CHECK(hipMallocAsync(&ws, need, s));
+    HParams h{};
+    h.ni = nx, h.nj = ny, h.lon0 = lon0, h.lat0 = lat0, h.lam_pole = lon_dp, h.r_pole = r_dp, h.eps = 1e-3;  // OGG:583
+    h.n_cols = n_cols, h.n_rows = n_lat_rows, h.lattice_M = M, h.row0_cell = j0;
+    h.q = ogg::quad_nodes_host(order);
+    h.h_i = static_cast<double*>(ws);
+    h.h_j = h.h_i + n_lat_rows * n_cols;
+    if (order == 2) {
+        dpole_h_kernel<2, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+        if (n_cell_rows > 0) dpole_h_kernel<2, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+    } else {
+        dpole_h_kernel<4, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+        if (n_cell_rows > 0) dpole_h_kernel<4, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
     }
-    return e;
+    OGG_LAUNCH_CHECK();
+    ReduceParams r{nx, n_cols, n_cell_rows, n_dx_rows, Re, h.h_i, h.h_j, dxq, dyq, daq};
+    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)n_dx_rows);
+    if (order == 2)
+        dpole_quad_reduce_kernel<2><<<grid, 256, 0, s>>>(r);
+    else
+        dpole_quad_reduce_kernel<4><<<grid, 256, 0, s>>>(r);
+    OGG_LAUNCH_CHECK();
+    if (!workspace) OGG_HIP_CHECK(hipFreeAsync(ws, s));
+    return OGG_OK;
+}
+
+int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                        double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
+                                        double* daq, void* stream) {
+    return ogg_displaced_pole_metrics_quad_ws_dev(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows, n_cell_rows, dxq, dyq,
+                                                  daq, nullptr, 0, stream);
 }
 
 }  // extern "C"

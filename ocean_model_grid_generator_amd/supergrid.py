@@ -204,6 +204,9 @@ class Supergrid(object):
                 elif s.kind == "bipolar":
                     b["ws_bytes"] = int(L.load().ogg_bipolar_quad_workspace_bytes(5, plan.Ni, s.Nj))
                     b["ws"] = torch.empty(b["ws_bytes"], dtype=torch.uint8, device=self.device)
+                elif s.kind == "dpole" and not plan.skip_metrics:
+                    b["ws_bytes"] = int(L.load().ogg_displaced_pole_quad_workspace_bytes(4, plan.Ni, b["n_cell"]))
+                    b["ws"] = torch.empty(b["ws_bytes"], dtype=torch.uint8, device=self.device)
                 self.buf[s.name] = b
 
     @staticmethod
@@ -339,9 +342,10 @@ class Supergrid(object):
                                                                    b["ws_bytes"], st))
                     else:
                         j0 = s.row0 + b["lo"]
-                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_dev", 4, p.Ni, s.Nj, p.lon0, s.lat0,
+                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_ws_dev", 4, p.Ni, s.Nj, p.lon0, s.lat0,
                                                                  s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
-                                                                 b["dy"].data_ptr(), b["area"].data_ptr(), st))
+                                                                 b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
+                                                                 b["ws_bytes"], st))
                 if s.kind != "bipolar":  # the bipolar mesh kernel already wrote angle_dx
                     self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
                                                           b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
