@@ -221,7 +221,8 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+            per_step = json.load(open(tfile)).get(args.workload, {}).get(dom)  # PMC bytes per step of that kernel
+            traffic = int(per_step / kernels[dom]["launches_per_step"]) if per_step else None
         out = {
             "metric": "supergrid cells/sec (coords+metrics)", "value": plan.cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -18,10 +18,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHORT = [("bipolar_quad_kernel", "bipolar_quad"), ("midas_angle_kernel<true", "midas_angle"), ("midas_angle_kernel<false", "angle_x"),
-         ("bipolar_mesh_kernel", "bipolar_mesh"), ("tile_latlon_kernel", "tile_latlon"), ("dpole_sweep_kernel<0", "dpole_mesh"),
-         ("dpole_sweep_kernel<4, 4, 2", "dpole_quad"), ("dpole_sweep_kernel<2, 2, 2", "dpole_quad"),
-         ("midas_fused", "latlon_fused")]
+SHORT = [("bipolar_quad_kernel", "bipolar_quad"), ("bipolar_tables_kernel", "bipolar_quad"), ("midas_angle_kernel<true", "midas_angle"),
+         ("midas_angle_kernel<false", "angle_x"), ("bipolar_mesh_kernel", "bipolar_mesh"), ("tile_latlon_kernel", "tile_latlon"),
+         ("dpole_sweep_kernel<0", "dpole_mesh"), ("dpole_h_kernel", "dpole_quad"), ("dpole_quad_reduce_kernel", "dpole_quad"),
+         ("latlon_fused_kernel", "latlon_fused")]
 
 
 def short(name):
@@ -59,12 +59,13 @@ def main():
         wr = 1024.0 * sum(write.get(key, [0])) / max(len(write.get(key, [0])), 1)
         lines.append("| %s | %d | %d | %.1f | %.1f | %.1f |" % (key[0], key[1], len(write.get(key, [])), rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
         t = table.setdefault(key[0], {"launch_bytes": []})
-        t["launch_bytes"].append(int(rd + wr))
+        t["launch_bytes"].append(int(rd + wr))  # one entry per distinct kernel launch of the step
     open(os.path.join(out, "%s_hbm_traffic_%s.md" % (tag, workload)), "w").write("\n".join(lines) + "\n")
     jf = os.path.join(out, "hbm_traffic.json")
     allj = json.load(open(jf)) if os.path.exists(jf) else {}
-    allj[workload] = {k: int(sum(v["launch_bytes"]) / len(v["launch_bytes"])) for k, v in table.items()}
-    allj["_source"] = "scripts/summarize_rocprof.py; mean HBM bytes per launch (read side x2), last updated for " + tag
+    allj[workload] = {k: int(sum(v["launch_bytes"])) for k, v in table.items()}
+    allj["_source"] = ("scripts/summarize_rocprof.py; HBM bytes per STEP of each logical kernel (all its launches; read side x2), "
+                       "last updated for " + tag)
     json.dump(allj, open(jf, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
 
