@@ -87,9 +87,11 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
 // results differ from the literal sequence only by rounding: <= 1e-14 relative where the cap latitude is >= 1.4 degrees
 // from the pole (measured against the oracle on the 1/8 degree lattice; 4e-15 at >= 4 degrees).  Nearer the pole the
 // LITERAL sequence loses digits (phis = 90 - small is rounded to 1 ulp of 90 before the cosine), and parity with the
-// reference means reproducing that, so lattice rows within OGG_BP_ALG_GAP_DEG (default 2) of the pole keep bp_point.
-OGG_DEV void bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
-                           double& hi2, double& hj2) {
+// reference means reproducing that: every point carries a guard (below) and the cells with a guarded point are
+// re-evaluated with bp_point by a fix-up kernel (about 0.4 % of the cells at 1/8 degree, around the two pole points).
+template <bool GUARD>
+OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
+                           double guard_k, double& hi2, double& hj2) {
     // bb1 = b (1+b) is row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them
     const double a = c.alpha2, b = r.beta2_inv;
     const double ab = a * b;
@@ -100,11 +102,25 @@ OGG_DEV void bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
     const double inv = rcp_nr(P * D);             // one reciprocal for both quotients
     const double rden = D * inv, E = P * inv;
     const double MM = rp2x4 * (E * E);            // M_inv^2
-    const double ccrr = (MM * (m1 * p1)) * (rden * rden);   // cos^2(phis) rden^2
+    const double cc = MM * (m1 * p1);             // cos^2(phis) = sin^2(2 atan(rp t))
+    const double ccrr = cc * (rden * rden);
     const double Mr = MM * rden;
-    hj2 = ccrr * (aa1 * bb1) + Mr * a1;
-    hi2 = ccrr * (1 + b) + Mr * ab;
+    const double t1j = ccrr * (aa1 * bb1), t1i = ccrr * (1 + b);
+    hj2 = t1j + Mr * a1;
+    hi2 = t1i + Mr * ab;
     // (the |beta2_inv| > HUGE case of OGG:86,94 only occurs on the exact j = ny row, which never takes this path)
+    //
+    // Exactness guard.  The literal sequence rounds phis = 90 - 2 atan(rp t)/PI_180 to a multiple of ulp(90) before taking
+    // its cosine, which perturbs cos^2(phis) by up to 2.4e-16 / atan(rp t) relative; the algebraic value does not have that
+    // perturbation, so where the cos^2 term carries weight w in h^2 the two differ by ~ w * 1.2e-16 / atan(rp t) in h.
+    // With atan(u) >= u/(1+u^2) = sqrt(cc)/2 the point is handed to the literal fix-up when w^2 > K * cc, i.e. when the
+    // difference could exceed ~ 2.4e-16 / sqrt(K) * ... (K = 1000: measured worst unflagged difference 8e-15 at 1/8 degree).
+    // Since w <= 1 a point can only be guarded where cos^2(phis) < 1/K, i.e. (phis <= grid latitude of the row) on the
+    // lattice rows with cos^2(lat) < 1/K: the rows below that latitude run the GUARD = false instantiation.
+    if (!GUARD) return false;
+    const double gi = t1i * t1i, gj = t1j * t1j;
+    const double kc = guard_k * cc;
+    return (gi > kc * (hi2 * hi2)) || (gj > kc * (hj2 * hj2));
 }
 
 // lams of OGG:50-64
@@ -215,6 +231,9 @@ struct QuadParams {
     int top_row;       // 1: this launch evaluates only dxq[ny][:] (exact j = ny lattice row) into band row out_row
     long out_row;
     long rows_per_chunk;  // cell rows one wave walks (its first lattice row is recomputed: 1/((N-1)*rows_per_chunk) extra)
+    double guard_k;       // exactness guard of bp_point_fast
+    unsigned* fix_count;  // number of cells handed to the literal fix-up ...
+    unsigned* fix_list;   // ... and their band-local linear indices out_r*nx + ci
     const BpRow* row_tab;  // [(N-1)*ny + 2]: unique lattice rows; entry (N-1)*ny is the ny-0.001 row, the last one is j = ny exactly
     const BpCol* col_tab;  // [(N-1)*nx + 1]: unique lattice columns
     double* dxq;
@@ -272,16 +291,20 @@ OGG_DEV double quad_weight_1d(int k) {  // w[k] of OGG:240 / 248, as selects (k 
 constexpr int QS_CELLS = 63;   // cells per wave strip
 constexpr int QS_WAVES = 4;    // strips per workgroup
 
-template <int N, bool FAITHFUL>
+template <int N, int MODE>
 struct RowEval {
     double dx[N];  // dx at this lane's columns ii = 0..N-2 and, in [N-1], at the right edge (from lane+1)
     double dy[N];
+    int guarded;   // any of these N points failed the exactness guard (always 0 on the literal path)
 };
 
-template <int N, bool FAITHFUL>
+constexpr int QM_FAST = 0, QM_GUARD = 1, QM_LITERAL = 2;  // per-point method of the strip kernel
+
+template <int N, int MODE>
 OGG_DEV void eval_lattice_row(const QuadParams& p, long u, const BpCol* col, double sx, double sy, double rp2x4, double rp2,
-                              RowEval<N, FAITHFUL>& o) {
+                              RowEval<N, MODE>& o) {
     constexpr int M = N - 1;
+    constexpr bool FAITHFUL = (MODE == QM_LITERAL);
     const BpRow r = p.row_tab[u];  // wave-uniform
     if (FAITHFUL) {
         // one point at a time (the libm calls of several points interleaved cost 225 VGPRs = 2 waves/SIMD); the column
@@ -306,23 +329,30 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, long u, const BpCol* col, dou
         }
     } else {
         const double bb1 = r.beta2_inv * (1 + r.beta2_inv), nsy = r.N_inv * sy;
+        int g_first = 0, g_any = 0;
 #pragma unroll
         for (int ii = 0; ii < M; ++ii) {
             double hi2, hj2;
             const double a1 = 1 - col[ii].alpha2;
-            bp_point_fast(r, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, hi2, hj2);
+            const bool g = bp_point_fast<MODE == QM_GUARD>(r, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, p.guard_k, hi2, hj2);
+            if (ii == 0) g_first = g;
+            g_any |= (int)g;
             o.dx[ii] = sqrt_nr(hi2) * sx;
             // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): sqrt_nr(0) would be 0 * inf
             o.dy[ii] = (hj2 > 0.0) ? sqrt_nr(hj2) * nsy : 0.0;
         }
+        o.guarded = 0;
+        if (MODE == QM_GUARD) o.guarded = g_any | __shfl_down(g_first, 1);  // the right edge is lane+1's first column
     }
+    if (FAITHFUL) o.guarded = 0;
     o.dx[M] = __shfl_down(o.dx[0], 1);
     o.dy[M] = __shfl_down(o.dy[0], 1);
 }
 
-template <int N, bool FAITHFUL>
+template <int N, int MODE>
 __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams p) {
     constexpr int M = N - 1;
+    constexpr bool FAITHFUL = (MODE == QM_LITERAL);
     const int lane = threadIdx.x & 63;
     const long strip = (long)blockIdx.x * QS_WAVES + (threadIdx.x >> 6);
     if (strip * QS_CELLS >= p.nx) return;  // wave-uniform
@@ -338,17 +368,18 @@ __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams 
     const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
     const double sx = (2 * kPi) / (double)p.nx, sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
     const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
-    RowEval<N, FAITHFUL> cur;
+    RowEval<N, MODE> cur;
     if (p.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
-        eval_lattice_row<N, FAITHFUL>(p, (long)M * p.ny + 1, col, sx, sy, rp2x4, rp2, cur);
+        eval_lattice_row<N, MODE>(p, (long)M * p.ny + 1, col, sx, sy, rp2x4, rp2, cur);
         if (cell_lane) p.dxq[p.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
         return;
     }
     const long r0 = p.row_begin + (long)blockIdx.y * p.rows_per_chunk;
     const long r1 = (r0 + p.rows_per_chunk < p.row_end) ? r0 + p.rows_per_chunk : p.row_end;
-    eval_lattice_row<N, FAITHFUL>(p, (long)M * r0, col, sx, sy, rp2x4, rp2, cur);
+    eval_lattice_row<N, MODE>(p, (long)M * r0, col, sx, sy, rp2x4, rp2, cur);
     for (long c = r0; c < r1; ++c) {
         const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
+        int guarded = cur.guarded;                                          // bottom-edge row (carried)
         double dyc[N];                                                      // dy down this lane's left edge
         double y2[(N <= 3) ? N * N : 1];
         double ysum = 0.0;
@@ -356,7 +387,10 @@ __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams 
         for (int k = 0; k < N; ++k) dyc[k] = 0.0;
 #pragma unroll(N <= 3 ? N : 1)
         for (int jj = 0; jj < N; ++jj) {
-            if (jj > 0) eval_lattice_row<N, FAITHFUL>(p, (long)M * c + jj, col, sx, sy, rp2x4, rp2, cur);
+            if (jj > 0) {
+                eval_lattice_row<N, MODE>(p, (long)M * c + jj, col, sx, sy, rp2x4, rp2, cur);
+                guarded |= cur.guarded;
+            }
             const double wj = quad_weight_1d<N>(jj);
 #pragma unroll
             for (int ii = 0; ii < N; ++ii) {
@@ -391,7 +425,77 @@ __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams 
                 da = d * d * ysum;
             }
             p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;                                      // OGG:185
+            if (MODE == QM_GUARD && guarded) p.fix_list[atomicAdd(p.fix_count, 1u)] = (unsigned)(out_r * p.nx + ci);
         }
+    }
+}
+
+// Literal re-evaluation (bp_point, OGG:41-95 operation for operation) of the cells the guard handed over: half a wave per
+// cell, one lane per Lobatto point (N*N <= 25 of 32 lanes), the lane of point 0 gathers the values with shuffles and sums
+// in the reference's order; overwrites the cell's dxq, dyq, daq (and dyq[.][nx] for the last cell of a row).  A cell is
+// re-evaluated iff one of ITS points is guarded, which depends on the cell alone: the result does not depend on tiling or
+// banding.
+template <int N>
+__global__ __launch_bounds__(64) void bipolar_quad_fixup_kernel(QuadParams p) {
+    constexpr int M = N - 1;
+    const unsigned count = *p.fix_count;
+    const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+    const int jj = (q < N * N) ? q / N : 0, ii = (q < N * N) ? q % N : 0;
+    for (unsigned k0 = blockIdx.x * 2; k0 < count; k0 += gridDim.x * 2) {  // wave-uniform trip count
+        const unsigned k = k0 + half;
+        const bool have = k < count;
+        const unsigned lin = have ? p.fix_list[k] : 0u;
+        const long out_r = lin / p.nx, ci = lin % p.nx;
+        const long cj = p.j0 + out_r;
+        double dx = 0.0, dy = 0.0;
+        if (have && q < N * N) {
+            const BpRow r = p.row_tab[M * cj + jj];
+            const BpCol c = p.col_tab[M * ci + ii];
+            double phis, rden, h_i, h_j;
+            bp_point(r, c, p.rp, phis, h_i, h_j, rden);
+            dx = h_i * 2 * kPi / (double)p.nx;                        // OGG:131
+            dy = h_j * (90 - p.lat0_bp) * kPi180 / (double)p.ny;      // OGG:132
+        }
+        const int base = half << 5;
+        double vdx[N * N], vdy[N * N];
+#pragma unroll
+        for (int t = 0; t < N * N; ++t) {
+            vdx[t] = __shfl(dx, base + t);
+            vdy[t] = __shfl(dy, base + t);
+        }
+        if (!have || q != 0) continue;
+        double yv[N];
+#pragma unroll
+        for (int t = 0; t < N; ++t) yv[t] = vdx[t];
+        p.dxq[out_r * p.nx + ci] = quad_average_1d<N>(yv) * p.Re;
+#pragma unroll
+        for (int t = 0; t < N; ++t) yv[t] = vdy[t * N];
+        p.dyq[out_r * (p.nx + 1) + ci] = quad_average_1d<N>(yv) * p.Re;
+        if (ci == p.nx - 1) {
+#pragma unroll
+            for (int t = 0; t < N; ++t) yv[t] = vdy[t * N + N - 1];
+            p.dyq[out_r * (p.nx + 1) + p.nx] = quad_average_1d<N>(yv) * p.Re;
+        }
+        double da;
+        if (N == 2) {
+            const double d = 1.0 / 2.0;
+            da = d * d * (vdx[0] * vdy[0] + vdx[1] * vdy[1] + vdx[(N == 2) ? 2 : 0] * vdy[(N == 2) ? 2 : 0] +
+                          vdx[(N == 2) ? 3 : 0] * vdy[(N == 2) ? 3 : 0]);
+        } else if (N == 3) {
+            const double d = 1.0 / 6.0;
+            auto Y = [&](int a, int b) { return vdx[(N == 3) ? a * 3 + b : 0] * vdy[(N == 3) ? a * 3 + b : 0]; };
+            da = d * d * (Y(0, 0) + Y(0, 2) + Y(2, 0) + Y(2, 2) + 4.0 * (Y(0, 1) + Y(1, 0) + Y(1, 2) + Y(2, 1) + 4.0 * Y(1, 1)));
+        } else {
+            const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
+            double ysum = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+#pragma unroll
+                for (int b = 0; b < N; ++b)
+                    ysum = ysum + (quad_weight_1d<N>(b) * quad_weight_1d<N>(a)) * (vdx[a * N + b] * vdy[a * N + b]);  // OGG:244/252
+            da = d * d * ysum;
+        }
+        p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;
     }
 }
 
@@ -433,12 +537,19 @@ QuadNodes make_nodes(int order) {  // OGG:191-204, host IEEE double
 }
 
 template <int N>
-int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double gap_deg, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
+size_t quad_workspace_bytes(long nx, long ny, long n_cell_rows) {
     constexpr int M = N - 1;
-    // table workspace: the caller's (graph-capturable: no allocation at all), or from the stream-ordered allocator (no host
-    // synchronisation, safe with concurrent streams)
+    const size_t tabs = (size_t)(M * ny + 2) * sizeof(BpRow) + (size_t)(M * nx + 1) * sizeof(BpCol);
+    return tabs + 16 + (size_t)(n_cell_rows > 0 ? n_cell_rows : 0) * nx * sizeof(unsigned);
+}
+
+template <int N>
+int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
+    constexpr int M = N - 1;
+    // workspace (row/column tables, fix-up counter and list): the caller's (graph-capturable: no allocation at all), or from
+    // the stream-ordered allocator (no host synchronisation, safe with concurrent streams)
     const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
-    const size_t need = (size_t)n_rows * sizeof(BpRow) + (size_t)n_cols * sizeof(BpCol);
+    const size_t need = quad_workspace_bytes<N>(p.nx, p.ny, n_cell_rows);
     void* ws = ext_ws;
     if (ext_ws)
         OGG_REQUIRE((size_t)ext_ws_bytes >= need, OGG_EARG, "bipolar quadrature workspace too small: %ld < %zu bytes", ext_ws_bytes, need);
@@ -446,47 +557,56 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double gap_deg, 
         OGG_HIP_CHECK(hipMallocAsync(&ws, need, s));
     BpRow* row_tab = static_cast<BpRow*>(ws);
     BpCol* col_tab = reinterpret_cast<BpCol*>(row_tab + n_rows);
+    unsigned* fix_count = reinterpret_cast<unsigned*>(col_tab + n_cols);
     p.row_tab = row_tab;
     p.col_tab = col_tab;
+    p.fix_count = fix_count;
+    p.fix_list = fix_count + 4;
+    p.guard_k = guard_k;
+    OGG_HIP_CHECK(hipMemsetAsync(fix_count, 0, 16, s));
     bipolar_tables_kernel<N><<<(unsigned)((n_rows + n_cols + 255) / 256), 256, 0, s>>>(p, row_tab, col_tab);
     OGG_LAUNCH_CHECK();
-    // Cell rows >= jf (within gap_deg degrees of cap latitude from the pole) keep the literal operation sequence, the
-    // others use the algebraic reduction (see bp_point_fast).  A function of the absolute cell row only.
-    // The top edge of the last "fast" cell row jf-1 is the lattice row j = jf: it must be at least gap_deg from the pole;
-    // the last cell row (whose top edge is the ny-0.001 row) is always literal.
-    long jf = (long)floor((double)p.ny * (1.0 - gap_deg / (90.0 - p.lat0_bp)));
-    if (!(jf > 0)) jf = 0;  // also catches gap = inf / NaN
-    if (jf > p.ny - 1) jf = p.ny - 1;
-    const long lo = p.j0, hi = p.j0 + n_cell_rows;
     const long n_strips = (p.nx + QS_CELLS - 1) / QS_CELLS;
     const unsigned gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);
-    // enough waves to fill 1024 SIMDs several times over, without recomputing more than ~1/(N-1) of the lattice rows
-    auto chunk_rows = [&](long rows, long target_waves) {
-        long rpc = (rows * n_strips + target_waves - 1) / target_waves;
-        return rpc < 1 ? 1L : (rpc > 32 ? 32L : rpc);
-    };
     p.top_row = 0;
-    if (lo < hi && lo < jf) {
-        p.row_begin = lo;
-        p.row_end = hi < jf ? hi : jf;
-        p.rows_per_chunk = chunk_rows(p.row_end - p.row_begin, 8192);
-        dim3 grid(gx, (unsigned)((p.row_end - p.row_begin + p.rows_per_chunk - 1) / p.rows_per_chunk));
-        bipolar_quad_kernel<N, false><<<grid, 64 * QS_WAVES, 0, s>>>(p);
+    // A point can only be guarded where cos^2(phis) < 1/K and phis never exceeds the grid latitude of its lattice row, so the
+    // cell rows whose top edge lies below acos(2/sqrt(K)) (a factor 4 of margin on cos^2) run without the guard.
+    long jg = 0;  // first cell row that carries the guard
+    if (guard_k > 4.0) {
+        const double lat_thr = acos(2.0 / sqrt(guard_k)) / kPi180;  // degrees
+        jg = (long)floor((double)p.ny * (lat_thr - p.lat0_bp) / (90.0 - p.lat0_bp)) - 1;
+    }
+    if (jg < 0) jg = 0;
+    if (jg > p.ny) jg = p.ny;
+    const long lo = p.j0, hi = p.j0 + n_cell_rows;
+    auto strips = [&](long b, long e, bool guard) -> int {
+        p.row_begin = b;
+        p.row_end = e;
+        // enough waves to fill 1024 SIMDs several times over, without recomputing more than a few % of the lattice rows
+        long rpc = ((e - b) * n_strips + 8191) / 8192;
+        p.rows_per_chunk = rpc < 1 ? 1 : (rpc > 32 ? 32 : rpc);
+        dim3 grid(gx, (unsigned)((e - b + p.rows_per_chunk - 1) / p.rows_per_chunk));
+        if (guard)
+            bipolar_quad_kernel<N, QM_GUARD><<<grid, 64 * QS_WAVES, 0, s>>>(p);
+        else
+            bipolar_quad_kernel<N, QM_FAST><<<grid, 64 * QS_WAVES, 0, s>>>(p);
+        OGG_LAUNCH_CHECK();
+        return OGG_OK;
+    };
+    if (lo < hi && lo < jg) {
+        if (int e = strips(lo, hi < jg ? hi : jg, false)) return e;
+    }
+    if (lo < hi && hi > jg) {
+        if (int e = strips(lo > jg ? lo : jg, hi, true)) return e;
+        p.row_begin = p.j0;
+        bipolar_quad_fixup_kernel<N><<<1024, 64, 0, s>>>(p);
         OGG_LAUNCH_CHECK();
     }
-    if (lo < hi && hi > jf) {
-        p.row_begin = lo > jf ? lo : jf;
-        p.row_end = hi;
-        p.rows_per_chunk = chunk_rows(p.row_end - p.row_begin, 4096);
-        dim3 grid(gx, (unsigned)((p.row_end - p.row_begin + p.rows_per_chunk - 1) / p.rows_per_chunk));
-        bipolar_quad_kernel<N, true><<<grid, 64 * QS_WAVES, 0, s>>>(p);
-        OGG_LAUNCH_CHECK();
-    }
-    if (n_dx_rows > n_cell_rows) {
+    if (n_dx_rows > n_cell_rows) {  // dxq[ny][:] from the exact j = ny lattice row: literal sequence
         p.top_row = 1;
         p.out_row = n_cell_rows;
         dim3 grid(gx, 1);
-        bipolar_quad_kernel<N, true><<<grid, 64 * QS_WAVES, 0, s>>>(p);
+        bipolar_quad_kernel<N, QM_LITERAL><<<grid, 64 * QS_WAVES, 0, s>>>(p);
         OGG_LAUNCH_CHECK();
     }
     if (!ext_ws) OGG_HIP_CHECK(hipFreeAsync(ws, s));
@@ -544,7 +664,12 @@ int ogg_bipolar_cap_ij_array_dev(long n_i, const double* i, long n_j, const doub
 
 long ogg_bipolar_quad_workspace_bytes(int order, long nx, long ny) {
     if (order < 2 || order > 5 || nx <= 0 || ny <= 0) return 0;
-    return (long)(((long)(order - 1) * ny + 2) * sizeof(BpRow) + ((long)(order - 1) * nx + 1) * sizeof(BpCol));
+    switch (order) {
+        case 2: return (long)quad_workspace_bytes<2>(nx, ny, ny);
+        case 3: return (long)quad_workspace_bytes<3>(nx, ny, ny);
+        case 4: return (long)quad_workspace_bytes<4>(nx, ny, ny);
+        default: return (long)quad_workspace_bytes<5>(nx, ny, ny);
+    }
 }
 
 int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
@@ -556,10 +681,10 @@ int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0
                     (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
                 OGG_ESHAPE, "ogg_bipolar_cap_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0, n_cell_rows,
                 n_dx_rows, ny);
-    // OGG_BP_ALG_GAP_DEG: distance from the pole (degrees of cap latitude) below which the literal operation sequence of
-    // the reference is kept; "inf" keeps it everywhere.  Default 2.0 (see bp_point_fast).
-    double gap = 2.0;
-    if (const char* e = getenv("OGG_BP_ALG_GAP_DEG")) gap = atof(e);
+    // OGG_BP_GUARD_K: threshold of the exactness guard (see bp_point_fast).  Default 1000; 0 hands every cell to the
+    // literal fix-up (slow; used by the tests to compare the two paths).
+    double gap = 1000.0;
+    if (const char* e = getenv("OGG_BP_GUARD_K")) gap = atof(e);
     QuadParams p{};
     p.nx = nx, p.ny = ny, p.lat0_bp = lat0_bp, p.lon_bp = lon_bp, p.rp = rp, p.Re = Re, p.j0 = j0;
     p.dxq = dxq, p.dyq = dyq, p.daq = daq, p.q = make_nodes(order);

@@ -102,14 +102,17 @@ class SupergridPlan(object):
             Nj_ncap -= 1
         bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=lat0_bp, lon_bp=self.lon0,
                          rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
-        # Row cost for the band split: the quadrature kernel keeps the reference's literal operation sequence for the cell
-        # rows within OGG_BP_ALG_GAP_DEG (default 2) degrees of the pole (see bp_point_fast in csrc/ogg_bipolar.hip); such a
-        # row costs ~4.8x a row of the algebraic path (measured: mesh + quadrature, 2.03 vs 0.42 us per row at 1/8 degree).
+        # Row cost for the band split of the cap.  The quadrature guards its algebraic per-point form near the two pole points
+        # (csrc/ogg_bipolar.hip, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K)) carry the guard (1.35x a
+        # plain row, measured at 1/8 degree: mesh + quadrature), and those above acos(1/sqrt(K)) also contain the cells the
+        # literal fix-up re-evaluates (2.6x).
         import os
-        gap = float(os.environ.get("OGG_BP_ALG_GAP_DEG", "2.0"))
-        jf = Nj_ncap * (1.0 - gap / (90.0 - lat0_bp))
-        jf = int(min(max(math.floor(jf) if jf == jf and jf > 0 else 0, 0), Nj_ncap - 1))
-        bp.row_cost = np.where(np.arange(Nj_ncap + 1) >= jf, 4.8, 1.0)
+        K = float(os.environ.get("OGG_BP_GUARD_K", "1000"))
+        if K > 4.0:
+            lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
+            guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
+            fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
+            bp.row_cost = np.where(lat_rows >= fix_lat, 2.6, np.where(lat_rows >= guard_lat, 1.35, 1.0))
         # Southern Ocean (OGG:1080-1103)
         lat0_SO = -78.0
         lenlat_SO = latUp_SO - lat0_SO
