@@ -12,6 +12,8 @@
 //   angle = atan2(+0, (lon_{i+1} - lon_{i-1}) cos(lat_j PI/180)) / (PI/180): the IEEE value of atan2(+0, p) is +0 for
 //           p > 0 or p = +0 and pi for p < 0 or p = -0.
 // tests/test_gpu_pipeline.py checks the bit-identity against the generic stencil kernel.
+#include <cstdlib>
+
 #include "ogg_common.h"
 #include "ogg_math.h"
 
@@ -43,7 +45,10 @@ struct RowScalars {
 __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
     __shared__ RowScalars s_row[LF_ROWS + 1];
     const int tid = threadIdx.x;
-    const long js = (long)blockIdx.y * p.rows_per_block;
+    // Row strips are taken grid-stride: the launch caps the number of resident workgroups (an HBM-write-bound kernel needs
+    // only a few waves per SIMD) so that a VALU-bound kernel running on another stream can share the CUs.
+    for (long strip = blockIdx.y; strip * p.rows_per_block < p.n_pt_rows; strip += gridDim.y) {
+    const long js = strip * p.rows_per_block;
     const long je = (js + p.rows_per_block < p.n_pt_rows) ? js + p.rows_per_block : p.n_pt_rows;
     const int nrows = (int)(je - js);
     // per-row scalars for rows js .. je (row je only when a cell row needs it)
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
 
     const long i = (long)blockIdx.x * LF_TX + tid;
     const long ni1 = p.ni1, ni = ni1 - 1;
-    if (i >= ni1) return;
+    if (i < ni1) {
     const double lon_c = p.lon[i];
     const double lon_r = p.lon[(i + 1 < ni1) ? i + 1 : i];
     const double lon_l = p.lon[(i > 0) ? i - 1 : 0];
@@ -104,6 +109,9 @@ __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
             }
         }
     }
+    }
+    __syncthreads();  // the row table is rewritten by the next strip
+    }
 }
 
 }  // namespace
@@ -120,7 +128,10 @@ extern "C" int ogg_latlon_supergrid_dev(long n_pt_rows, long n_cell_rows, long n
     long rpb = (n_pt_rows * gx + 2047) / 2048;  // aim at >= 2048 workgroups (8 per CU)
     rpb = rpb < 4 ? 4 : (rpb > LF_ROWS ? LF_ROWS : rpb);
     FusedParams p{n_pt_rows, metrics ? n_cell_rows : 0, ni1, (int)rpb, lat1d, lon1d, Re, pow(Re, 2.0), metrics, x, y, dx, dy, area, angle};
-    dim3 grid((unsigned)gx, (unsigned)((n_pt_rows + rpb - 1) / rpb));
+    long gy = (n_pt_rows + rpb - 1) / rpb;
+    static const long max_wg = getenv("OGG_FUSED_MAX_WG") ? atol(getenv("OGG_FUSED_MAX_WG")) : 128;  // ~100 workgroups already saturate the HBM write path (measured)
+    if (gx * gy > max_wg) gy = (max_wg + gx - 1) / gx;
+    dim3 grid((unsigned)gx, (unsigned)gy);
     latlon_fused_kernel<<<grid, LF_TX, 0, ogg::as_stream(stream)>>>(p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
