@@ -57,7 +57,7 @@ def band_points(plan, rank, world, sg_mod):
         lo, hi = sg_mod.Supergrid.rows_of(s, rank, world)
         n = (hi - lo) * ni1
         if s.kind in ("mercator", "latlon"):
-            pts.setdefault("latlon_fused", []).append(n)
+            pts["latlon_fused"] = [pts.get("latlon_fused", [0])[0] + n]   # all lat-lon bands go out in one launch
             pts.setdefault("tile_latlon", []).append(n)
             pts.setdefault("midas_angle", []).append(n)
         elif s.kind == "bipolar":

@@ -99,6 +99,20 @@ int ogg_angle_x(long nj1, long ni1, const double* x, const double* y, double* an
  * angle_dx (n_pt_rows x ni1), dx (n_pt_rows x ni1-1) and dy (n_cell_rows x ni1), area (n_cell_rows x ni1-1) from the two
  * 1-D axes alone; bit-identical to ogg_tile_latlon_dev + ogg_grid_metrics_midas_dev.  lat1d must hold n_pt_rows entries,
  * plus one more when n_cell_rows == n_pt_rows (the row above the band).  metrics = 0 writes only x, y, angle_dx. */
+typedef struct {
+    int axis_kind;  /* 0: lat[k] = a0 + (k*len)/denom (OGG:835); 1: Mercator, lat[k] = atan(sinh((y0+k)/R))*(180/pi), R = Ni/(2 pi)
+                       (OGG:336); 2: lat[k] = lat1d[k] (device array, e.g. the enhanced-equator axis) */
+    double a0, len, denom;
+    long long y0;
+    const double* lat1d;
+    long k0;           /* axis index of the band's first point row */
+    long n_pt_rows;    /* point rows of the band (x, y, dx, angle_dx) */
+    long n_cell_rows;  /* cell rows of the band (dy, area); row n_cell_rows of the axis must exist when == n_pt_rows */
+    double *x, *y, *dx, *dy, *area, *angle;
+} ogg_latlon_band;
+/* Up to 4 lat-lon bands in one launch, axes evaluated in the kernel: lon[i] = lon0 + (i*lenlon)/(ni1-1) (OGG:431, 834). */
+int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band* bands, long ni1, double lon0, double lenlon, double Re,
+                                   int metrics, void* stream);
 int ogg_latlon_supergrid_dev(long n_pt_rows, long n_cell_rows, long ni1, const double* lat1d, const double* lon1d, double Re,
                              int metrics, double* x, double* y, double* dx, double* dy, double* area, double* angle,
                              void* stream);

@@ -17,6 +17,13 @@ c_long, c_int, c_double, c_void_p, c_longlong = ctypes.c_long, ctypes.c_int, cty
 _dp = ctypes.POINTER(ctypes.c_double)
 _llp = ctypes.POINTER(ctypes.c_longlong)
 
+class LatlonBand(ctypes.Structure):
+    """ogg_latlon_band of include/ogg_hip.h"""
+    _fields_ = [("axis_kind", c_int), ("a0", c_double), ("len", c_double), ("denom", c_double), ("y0", c_longlong),
+                ("lat1d", c_void_p), ("k0", c_long), ("n_pt_rows", c_long), ("n_cell_rows", c_long), ("x", c_void_p),
+                ("y", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p), ("angle", c_void_p)]
+
+
 # name -> argtypes; every function returns int except the two string getters.  Must list EVERY symbol of ogg_hip.h
 # (tests/test_abi.py checks this list against the header).
 SIGNATURES = {
@@ -84,6 +91,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p],
     "ogg_monotonic_bounding": [c_long, c_long, c_void_p, c_double],
     "ogg_monotonic_bounding_dev": [c_long, c_long, c_void_p, c_double, c_void_p],
+    "ogg_latlon_supergrid_multi_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int, c_void_p],
     "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],

@@ -249,6 +249,7 @@ __global__ void bipolar_tables_kernel(QuadParams p, BpRow* row_tab, BpCol* col_t
     constexpr int M = N - 1;
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
+    if (k == 0) *p.fix_count = 0u;  // the fix-up list of this call starts empty (this kernel precedes the quadrature kernels)
     if (k < n_rows) {
         double jv;
         if (k == M * p.ny)
@@ -563,7 +564,6 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, 
     p.fix_count = fix_count;
     p.fix_list = fix_count + 4;
     p.guard_k = guard_k;
-    OGG_HIP_CHECK(hipMemsetAsync(fix_count, 0, 16, s));
     bipolar_tables_kernel<N><<<(unsigned)((n_rows + n_cols + 255) / 256), 256, 0, s>>>(p, row_tab, col_tab);
     OGG_LAUNCH_CHECK();
     const long n_strips = (p.nx + QS_CELLS - 1) / QS_CELLS;

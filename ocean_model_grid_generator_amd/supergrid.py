@@ -251,24 +251,40 @@ class Supergrid(object):
         """Coordinates of this rank's bands (optionally of one sub-grid / of some kinds of sub-grid only)."""
         p, st = self.plan, self._stream()
         ni1 = p.Ni + 1
-        if only is None:
+        if only is None and self.latlon != "fused":
             L.call("ogg_linear_axis_dev", ni1, p.lon0, p.lenlon, float(p.Ni), self.lon1d.data_ptr(), st)
+        if self.latlon == "fused":
+            bands = []
+            for s in p.subs:
+                b = self.buf[s.name]
+                if b["n"] == 0 or not self._selected(s, only, kinds) or s.kind not in ("mercator", "latlon"):
+                    continue
+                band = L.LatlonBand()
+                if s.kind == "mercator":
+                    band.axis_kind, band.y0 = 1, s.y0
+                else:
+                    band.axis_kind, band.a0, band.len, band.denom = 0, s.lat0, s.lenlat, float(s.lnj)
+                band.k0, band.n_pt_rows, band.n_cell_rows = s.row0 + b["lo"], b["n"], b["n_cell"]
+                band.x, band.y, band.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
+                band.dx = b["dx"].data_ptr()
+                band.dy = b["dy"].data_ptr() if b["n_cell"] else None
+                band.area = b["area"].data_ptr() if b["n_cell"] else None
+                bands.append(band)
+            if bands:
+                arr = (L.LatlonBand * len(bands))(*bands)
+                self._timed("latlon_fused", lambda: L.call("ogg_latlon_supergrid_multi_dev", len(bands), arr, ni1, p.lon0, p.lenlon, p.Re,
+                                                           0 if p.skip_metrics else 1, st))
         for s in p.subs:
             b = self.buf[s.name]
             if b["n"] == 0 or not self._selected(s, only, kinds):
                 continue
             if s.kind in ("mercator", "latlon"):
+                if self.latlon == "fused":
+                    continue
                 if s.kind == "mercator":
                     L.call("ogg_mercator_axis_dev", p.Ni, s.y0, s.n_axis, b["axis"].data_ptr(), st)
                 else:
                     L.call("ogg_linear_axis_dev", s.lnj + 1, s.lat0, s.lenlat, float(s.lnj), b["axis"].data_ptr(), st)
-                if self.latlon == "fused":
-                    self._timed("latlon_fused", lambda: L.call(
-                        "ogg_latlon_supergrid_dev", b["n"], b["n_cell"], ni1, self._p(b["axis"], s.row0 + b["lo"]), self.lon1d.data_ptr(),
-                        p.Re, 0 if p.skip_metrics else 1, b["x"].data_ptr(), b["y"].data_ptr(), b["dx"].data_ptr(),
-                        b["dy"].data_ptr() if b["n_cell"] else None, b["area"].data_ptr() if b["n_cell"] else None,
-                        b["angle_dx"].data_ptr(), st))
-                    continue
                 rows = b["n"] + (1 if (b["needs_halo"] and self.halo == "recompute") else 0)
                 self._timed("tile_latlon", lambda: L.call("ogg_tile_latlon_dev", rows, ni1, self._p(b["axis"], s.row0 + b["lo"]),
                                                           self.lon1d.data_ptr(), b["x"].data_ptr(), b["y"].data_ptr(), st))
