@@ -386,7 +386,9 @@ class Supergrid(object):
             return
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
-            self._side = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            import os
+            prio = int(os.environ.get("OGG_SIDE_PRIORITY", "0"))
+            self._side = [torch.cuda.Stream(self.device, priority=prio), torch.cuda.Stream(self.device, priority=prio)]
         fork = torch.cuda.Event()
         fork.record(main)
         caps = [s for s in self.plan.subs if s.kind in ("bipolar", "dpole")]
