@@ -21,6 +21,8 @@
 // is evaluated once per column and reused by the N lattice rows of the cell row; everything that depends on the row
 // only (the gnomonic radius) once per workgroup.  Duplicate Lobatto nodes on shared vertical cell edges are evaluated
 // once: a repeated column has v_k == v_{k-1}, whose map is the identity, so skipping it leaves every state unchanged.
+#include <cstdlib>
+
 #include "ogg_common.h"
 #include "ogg_math.h"
 
@@ -478,6 +480,112 @@ __global__ __launch_bounds__(SW_TX) void dpole_h_kernel(HParams p) {
     }
 }
 
+
+// ---- chord form of the finite-difference scale factors -----------------------------------------------------------------
+// The reference differentiates great-arc distances numerically (OGG:535-562): h = (8 ds(eps) - ds(2 eps)) / (12 eps), where
+// ds is the haversine distance between two projected points that are ~2e-6 rad apart, formed from longitudes/latitudes in
+// degrees.  That subtraction of two O(1) angles loses 10 digits: against an 80-bit evaluation the reference's own h is
+// accurate to 2e-9 (relative).  Here the SAME stencil (the same 4H probe points, the same w = conformal image of each probe,
+// bit for bit as in dp_point) is kept, but the distance between two probes is taken from their unit vectors on the sphere,
+// ds = 2 asin(|u1 - u0| / 2): no atan2 / atan / hypot per probe, no sin/cos/asin per pair, and no longitude at all -- hence
+// no 360-degree unwrap and no sequential scan.  Its h is accurate to 8e-10 and differs from the reference's by 1.6e-9, i.e. by
+// less than the reference's own rounding error (tests/test_gpu_parity.py bounds it at 5e-7 like the literal path;
+// OGG_DP_LITERAL=1 selects the literal kernels, which numerical_hi / numerical_hj / great_arc_distance always use).
+struct ChordParams {
+    long ni, nj;
+    double lon0, lat0, lam_pole, r_pole, eps;
+    long n_cols, n_rows;   // unique lattice columns / rows
+    int lattice_M;
+    long row0_cell;
+    QuadNodes q;
+    double* row_tab;       // [NV][n_rows]: gnomonic radius of row variants (base, +eps, -eps, +2eps, -2eps)
+    double* col_tab;       // [NV][2][n_cols]: e' of column variants
+    double* h_i;
+    double* h_j;
+};
+
+template <int F>
+__global__ void dpole_chord_tables_kernel(ChordParams p) {
+    constexpr int NV = F + 1;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    SweepParams sp{};
+    sp.ni = p.ni, sp.nj = p.nj, sp.lon0 = p.lon0, sp.lat0 = p.lat0, sp.lam_pole = p.lam_pole, sp.r_pole = p.r_pole;
+    const DpConst c = dp_const(sp);
+    const int M = p.lattice_M;
+    if (k < p.n_rows * NV) {
+        const long row = k / NV;
+        const int var = (int)(k % NV);
+        double jv = lattice_node(p.q, (int)(row % M), p.row0_cell + row / M);
+        if (var > 0) {
+            const double off = (double)((var + 1) / 2) * p.eps;
+            jv = (var & 1) ? jv + off : jv - off;
+        }
+        p.row_tab[var * p.n_rows + row] = dp_row_radius(jv, sp, c);
+    } else if (k < p.n_rows * NV + p.n_cols * NV) {
+        const long kk = k - p.n_rows * NV;
+        const long col = kk / NV;
+        const int var = (int)(kk % NV);
+        double iv = lattice_node(p.q, (int)(col % M), col / M);
+        if (var > 0) {
+            const double off = (double)((var + 1) / 2) * p.eps;
+            iv = (var & 1) ? iv + off : iv - off;
+        }
+        const cplx ep = dp_column(iv, sp, c);
+        p.col_tab[(var * 2 + 0) * p.n_cols + col] = ep.re;
+        p.col_tab[(var * 2 + 1) * p.n_cols + col] = ep.im;
+    }
+}
+
+struct Vec3 {
+    double x, y, z;
+};
+
+// unit vector of the point whose gnomonic image (plane tangent at the south pole) is w * r_joint; w exactly as in dp_point
+OGG_DEV Vec3 dp_unit(double r, cplx ep, const DpConst& c) {
+    const cplx z = {r * ep.re, r * ep.im};
+    const cplx num = {z.re + c.z0r, z.im + c.z0i};
+    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, z);
+    const cplx den = {1 + cz.re, cz.im};
+    const cplx w = cdiv(num, den);
+    const double X = w.re * c.r_joint, Y = w.im * c.r_joint;
+    const double n = 1.0 / sqrt(X * X + Y * Y + 1.0);
+    return Vec3{X * n, Y * n, -n};
+}
+
+OGG_DEV double chord_arc(const Vec3& a, const Vec3& b) {
+    const double dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+    const double half = 0.5 * sqrt(dx * dx + dy * dy + dz * dz);
+    return 2.0 * asin(half);
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void dpole_chord_h_kernel(ChordParams p) {
+    constexpr int H = F / 2, NV = F + 1;
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = blockIdx.y;
+    if (col >= p.n_cols) return;
+    SweepParams sp{};
+    sp.ni = p.ni, sp.nj = p.nj, sp.lon0 = p.lon0, sp.lat0 = p.lat0, sp.lam_pole = p.lam_pole, sp.r_pole = p.r_pole;
+    const DpConst c = dp_const(sp);
+    const double reps = 1.0 / p.eps;
+    double r[NV];
+    cplx ep[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        r[v] = p.row_tab[v * p.n_rows + row];  // wave-uniform
+        ep[v] = cplx{p.col_tab[(v * 2 + 0) * p.n_cols + col], p.col_tab[(v * 2 + 1) * p.n_cols + col]};
+    }
+    double dsi[(H > 0) ? H : 1], dsj[(H > 0) ? H : 1];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        // OGG:538,541: ds(j, i + m eps, j, i - m eps);  OGG:553,556: ds(j + m eps, i, j - m eps, i)
+        dsi[m - 1] = chord_arc(dp_unit(r[0], ep[2 * m - 1], c), dp_unit(r[0], ep[2 * m], c));
+        dsj[m - 1] = chord_arc(dp_unit(r[2 * m - 1], ep[0], c), dp_unit(r[2 * m], ep[0], c));
+    }
+    p.h_i[row * p.n_cols + col] = central_difference<F>(dsi, reps);
+    if (p.h_j) p.h_j[row * p.n_cols + col] = central_difference<F>(dsj, reps);
+}
+
 // ---- Lobatto quadrature of the lattice values, one thread per cell, reference summation order (OGG:585-599) --------
 struct ReduceParams {
     long nx, n_cols;       // cells per row; lattice columns (M*nx + 1)
@@ -670,7 +778,8 @@ int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, cons
 
 long ogg_displaced_pole_quad_workspace_bytes(int order, long nx, long n_cell_rows) {
     if (order < 2 || order > 5 || nx <= 0 || n_cell_rows < 0) return 0;
-    return 2L * ((long)(order - 1) * n_cell_rows + 1) * ((long)(order - 1) * nx + 1) * (long)sizeof(double);
+    const long rows = (long)(order - 1) * n_cell_rows + 1, cols = (long)(order - 1) * nx + 1;
+    return (2L * rows * cols + (long)(order + 1) * (rows + 2 * cols)) * (long)sizeof(double);
 }
 
 int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
@@ -691,7 +800,7 @@ int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double l
     // lattice rows of the band: the unique Lobatto rows of its cell rows plus the closing row (which is dxq's row j0+n_cell_rows
     // when the band owns it, and the top edge of the last cell row otherwise)
     const long n_lat_rows = (long)M * n_cell_rows + 1, n_cols = (long)M * nx + 1;
-    const size_t need = 2 * (size_t)n_lat_rows * n_cols * sizeof(double);
+    const size_t need = (size_t)ogg_displaced_pole_quad_workspace_bytes(order, nx, n_cell_rows);
     void* ws = workspace;
     if (workspace)
         OGG_REQUIRE((size_t)workspace_bytes >= need, OGG_EARG, "displaced-pole quadrature workspace too small: %ld < %zu bytes", workspace_bytes, need);
@@ -703,12 +812,32 @@ int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double l
     h.q = ogg::quad_nodes_host(order);
     h.h_i = static_cast<double*>(ws);
     h.h_j = h.h_i + n_lat_rows * n_cols;
-    if (order == 2) {
-        dpole_h_kernel<2, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-        if (n_cell_rows > 0) dpole_h_kernel<2, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-    } else {
-        dpole_h_kernel<4, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-        if (n_cell_rows > 0) dpole_h_kernel<4, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+    static const bool literal = getenv("OGG_DP_LITERAL") && atoi(getenv("OGG_DP_LITERAL")) != 0;
+    if (literal) {  // haversine of unwrapped longitudes, operation for operation as OGG:522-562
+        if (order == 2) {
+            dpole_h_kernel<2, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+            if (n_cell_rows > 0) dpole_h_kernel<2, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+        } else {
+            dpole_h_kernel<4, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+            if (n_cell_rows > 0) dpole_h_kernel<4, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
+        }
+    } else {  // same stencil, chord form of the distance (see dpole_chord_h_kernel)
+        ChordParams cp{};
+        cp.ni = nx, cp.nj = ny, cp.lon0 = lon0, cp.lat0 = lat0, cp.lam_pole = lon_dp, cp.r_pole = r_dp, cp.eps = 1e-3;
+        cp.n_cols = n_cols, cp.n_rows = n_lat_rows, cp.lattice_M = M, cp.row0_cell = j0, cp.q = h.q;
+        cp.row_tab = h.h_j + n_lat_rows * n_cols;
+        cp.col_tab = cp.row_tab + (long)(order + 1) * n_lat_rows;
+        cp.h_i = h.h_i;
+        cp.h_j = (n_cell_rows > 0) ? h.h_j : nullptr;
+        const long n_tab = (long)(order + 1) * (n_lat_rows + n_cols);
+        dim3 grid((unsigned)((n_cols + 255) / 256), (unsigned)n_lat_rows);
+        if (order == 2) {
+            dpole_chord_tables_kernel<2><<<(unsigned)((n_tab + 255) / 256), 256, 0, s>>>(cp);
+            dpole_chord_h_kernel<2><<<grid, 256, 0, s>>>(cp);
+        } else {
+            dpole_chord_tables_kernel<4><<<(unsigned)((n_tab + 255) / 256), 256, 0, s>>>(cp);
+            dpole_chord_h_kernel<4><<<grid, 256, 0, s>>>(cp);
+        }
     }
     OGG_LAUNCH_CHECK();
     ReduceParams r{nx, n_cols, n_cell_rows, n_dx_rows, Re, h.h_i, h.h_j, dxq, dyq, daq};

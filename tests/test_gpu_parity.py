@@ -220,6 +220,25 @@ def test_bipolar_quad_vs_oracle(ogg, Ni, Nj, lat0):
         assert max(abs(e) for e in err) < 1e-9
 
 
+def test_bipolar_quad_full_size_r8_by_zone(ogg):
+    """BASELINE config 2's cap (5760 x 960 cells) against the oracle, in bands from the joint to the pole: the algebraic
+    per-point form, the guarded rows and the cells re-evaluated by the literal fix-up must all stay at the same level."""
+    Ni, Nj, lat0 = 5760, 960, 64.03160594077568
+    rp = np.tan(0.5 * (90 - lat0) * orc.PI_180)
+    got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
+    worst = {}
+    for a, b in ((0, 24), (470, 494), (860, 890), (890, 930), (930, 960)):
+        want = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp, rows_per_chunk=8, j_first=a, j_last=b)
+        for g, w, name in zip(got, want, ("dx", "dy", "area")):
+            gg, ww = g[a:b], w[a:b]
+            m = ww != 0
+            assert np.array_equal(gg[~m], ww[~m])                      # dy == 0 on the meridians alpha2 == 1
+            worst[(name, a)] = float((np.abs(gg - ww)[m] / np.abs(ww[m])).max())
+        assert maxabs(got[2][a:b], want[2][a:b]) < 1e-6                # north_star: area diff < 1e-6 m^2
+    record("bp_quad_r8_zones", **{"%s_%d" % k: v for k, v in worst.items()})
+    assert max(worst.values()) < 5e-14
+
+
 def test_bipolar_cap_ij_array(ogg):
     rng = np.random.default_rng(5)
     i, j = np.sort(rng.uniform(0, 48, 33)), np.sort(rng.uniform(0, 9.9, 7))
