@@ -236,7 +236,8 @@ def main():
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
-                         "note": "cap quadratures are fp64-VALU bound (DESIGN.md); midas_angle is the HBM-bound kernel"},
+                         "note": "per-kernel durations from the sequential events pass; latlon_fused (78 % of the cells) is the HBM-bound "
+                                 "kernel, the cap kernels are fp64-VALU bound (DESIGN.md 4)"},
             "kernels": kernels,
         }
         if world == 1 and args.cpu_sample_div > 0:

@@ -156,9 +156,9 @@ extern "C" int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band
     for (int k = 0; k < p.n_bands; ++k) p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
     p.ni1 = ni1, p.lon0 = lon0, p.lenlon = lenlon, p.Ni = (double)(ni1 - 1);
     p.rows_per_block = (int)rpb, p.Re = Re, p.Re2 = pow(Re, 2.0), p.metrics = metrics;
-    // Resident workgroups: ~90 (measured optimum; 69 are too few) already saturate the HBM write path on a large launch (measured), which leaves the CUs to a
+    // Resident workgroups: ~115 (measured: 92 already slow the kernel by 20 %, 69 by 60 %) saturate the HBM write path on a large launch (measured), which leaves the CUs to a
     // concurrent VALU-bound kernel; small launches are latency-bound and take the whole chip.
-    long max_wg = points >= 8000000 ? 92 : (points >= 2000000 ? 512 : 2048);
+    long max_wg = points >= 8000000 ? 115 : (points >= 2000000 ? 512 : 2048);
     if (const char* e = getenv("OGG_FUSED_MAX_WG")) max_wg = atol(e);
     long gy = p.strip0[p.n_bands];
     if (gx * gy > max_wg) gy = (max_wg + gx - 1) / gx;
