@@ -294,6 +294,9 @@ class Supergrid(object):
             elif s.kind == "dpole":
                 self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
                                                          s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(), st))
+                # angle_dx of the cap reads the mesh back: same stream, right behind it (the bipolar mesh kernel fuses its angle)
+                self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
+                                                      b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
 
     def exchange_halo(self):
         """First x/y row of the band above -> halo row of this band (MIDAS sub-grids only)."""
@@ -365,9 +368,6 @@ class Supergrid(object):
                                                                  s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
                                                                  b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
                                                                  b["ws_bytes"], st))
-                if s.kind != "bipolar":  # the bipolar mesh kernel already wrote angle_dx
-                    self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
-                                                          b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
 
     def step(self, time_kernels=False):
         """One full pass of the hot path for this rank's bands; outputs stay in HBM."""
@@ -385,20 +385,21 @@ class Supergrid(object):
             self.phase_b()
             return
         main = torch.cuda.current_stream(self.device)
-        if self._side is None:
-            import os
-            prio = int(os.environ.get("OGG_SIDE_PRIORITY", "0"))
-            self._side = [torch.cuda.Stream(self.device, priority=prio), torch.cuda.Stream(self.device, priority=prio)]
+        caps = [s for s in self.plan.subs if s.kind in ("bipolar", "dpole")]
+        # independent pieces of work: mesh (+ angle) and quadrature of every cap, one stream each
+        tasks = []
+        for s in caps:
+            tasks.append(lambda s=s: self.phase_a(only=s.name))
+            tasks.append(lambda s=s: self.phase_b(only=s.name))
+        if self._side is None or len(self._side) < len(tasks):
+            self._side = [torch.cuda.Stream(self.device) for _ in tasks]
         fork = torch.cuda.Event()
         fork.record(main)
-        caps = [s for s in self.plan.subs if s.kind in ("bipolar", "dpole")]
         joins = []
-        for k, s in enumerate(caps):
-            st = self._side[k % 2]
+        for st, task in zip(self._side, tasks):
             st.wait_event(fork)
             with torch.cuda.stream(st):
-                self.phase_a(only=s.name)
-                self.phase_b(only=s.name)
+                task()
                 e = torch.cuda.Event()
                 e.record(st)
                 joins.append(e)
