@@ -4,23 +4,20 @@
 //   great_arc_distance, numerical_hi/hj      OGG:522-562
 //   displacedPoleCap_metrics_quad            OGG:565-601
 //
-// One templated row-sweep kernel serves three uses:
-//   MESH  (F = 0)      lam, phi on a lattice of (fractional) indices          -> K5
-//   EMIT  (F = 2,4,6)  finite-difference scale factors h_i, h_j on a lattice   -> numerical_hi / numerical_hj
-//   QUAD  (F = N)      Lobatto quadrature of h_i, h_j, h_i*h_j per cell        -> K6
+// Kernels:
+//   dpole_mesh_kernel                    lam, phi on a lattice of (fractional) indices, exact 360-degree unwrap     -> K5
+//   dpole_direct_kernel                  displacedPoleCap_projection on explicit grids / bare monotonic_bounding
+//   dpole_h_kernel<F, group>             literal finite-difference scale factors h_i / h_j (numerical_hi / _hj)
+//   dpole_chord_tables / _h_kernel<F>    the same stencil with the chord form of the great-arc distance            -> K6
+//   dpole_quad_reduce_kernel<N>          Lobatto quadrature of h_i, h_j, h_i*h_j per cell                           -> K6
 //
-// monotonic_bounding is a sequential scan along i: column k is lowered by 360 iff v_k - x_{k-1} > 100 where x_{k-1}
-// is the ALREADY ADJUSTED previous column.  With s_k in {0,1} the "was lowered" state, s_k = f_k(s_{k-1}) with
+// monotonic_bounding is a sequential scan along i: column k is lowered by 360 iff v_k - x_{k-1} > 100 where x_{k-1} is the
+// ALREADY ADJUSTED previous column.  With s_k in {0,1} the "was lowered" state, s_k = f_k(s_{k-1}) with
 // f_k(0) = [v_k - v_{k-1} > 100], f_k(1) = [v_k - (v_{k-1} - 360) > 100] -- a composition of 1-bit maps, which is
-// associative.  A workgroup sweeps a lattice row in chunks of SW_TX columns; inside a chunk the maps of all probes
-// (bit-packed, one bit per probe) are composed with a wave64 shuffle scan plus a 4-entry LDS carry, and the state and
-// raw value of the last column are carried to the next chunk.  The comparison values are formed exactly as the
-// reference forms them, so the unwrap is bit-faithful to the sequential loop.
-//
-// K6 is fp64-VALU bound.  Everything that depends on the column only (sincos of the longitude, the first Moebius map)
-// is evaluated once per column and reused by the N lattice rows of the cell row; everything that depends on the row
-// only (the gnomonic radius) once per workgroup.  Duplicate Lobatto nodes on shared vertical cell edges are evaluated
-// once: a repeated column has v_k == v_{k-1}, whose map is the identity, so skipping it leaves every state unchanged.
+// associative.  A workgroup sweeps a row in chunks of SW_TX columns; inside a chunk the maps of all probes (bit-packed,
+// one bit per probe) are composed with a wave64 shuffle scan plus a 4-entry LDS carry, and the state and raw value of the
+// last column are carried to the next chunk.  The comparison values are formed exactly as the reference forms them, so
+// the unwrap is bit-faithful to the sequential loop.
 #include <cstdlib>
 
 #include "ogg_common.h"
@@ -36,27 +33,18 @@ using namespace ogg;
 
 constexpr int SW_TX = 256;
 constexpr int SW_WAVES = SW_TX / 64;
-constexpr int MODE_MESH = 0, MODE_EMIT = 1, MODE_QUAD = 2;
 
 struct SweepParams {
     // geometry of the cap (OGG:478-495)
     long ni, nj;
     double lon0, lat0, lam_pole, r_pole;
-    double eps, Re;
-    // lattice
-    long n_cols;          // columns per lattice row (MESH/EMIT: n_i; QUAD: unique columns M*nx+1)
-    long n_rows;          // MESH/EMIT: lattice rows; QUAD: cell rows handled by this launch
-    const double* i_arr;  // MESH/EMIT: column indices or NULL for 0,1,2,...
-    const double* j_arr;  // MESH/EMIT: row indices or NULL for j0, j0+1, ...
-    long j0;              // first row (MESH iota) / first cell row of the band (QUAD)
-    long nx, ny;          // QUAD: cells
-    int top_row;          // QUAD: 1 = only dxq[ny][:]
-    long out_row;         // QUAD top_row: band-local output row
-    QuadNodes q;
-    // outputs
-    double* out0;  // MESH lam | EMIT h_i | QUAD dxq
-    double* out1;  // MESH phi | EMIT h_j | QUAD dyq
-    double* out2;  //                      QUAD daq
+    // lattice of the mesh kernel
+    long n_cols;          // columns per row
+    const double* i_arr;  // column indices or NULL for 0,1,2,...
+    const double* j_arr;  // row indices or NULL for j0, j0+1, ...
+    long j0;
+    double* out0;         // lam
+    double* out1;         // phi
 };
 
 struct DpConst {
@@ -198,196 +186,37 @@ OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
     return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
 }
 
-// F: finite-difference order (0 for MESH).  N: lattice rows per workgroup (quadrature order for QUAD, 1 otherwise).
-template <int F, int N, int MODE>
-__global__ __launch_bounds__(SW_TX) void dpole_sweep_kernel(SweepParams p) {
-    constexpr int H = F / 2;                        // probe distances 1..H (in units of eps)
-    constexpr int HH = (H > 0) ? H : 1;
-    constexpr int NP = (MODE == MODE_MESH) ? 1 : 2 * F;  // probes per lattice point: H x {+,-} x {i, j}
-    constexpr int NV = (MODE == MODE_MESH) ? 1 : 1 + F;  // distinct column (and row) variants: base, +-m*eps
-    constexpr int M = (N > 1) ? N - 1 : 1;          // unique columns per cell (QUAD)
-    constexpr int STEP = (MODE == MODE_QUAD) ? (255 / M) * M : SW_TX;  // new columns per chunk
-    constexpr int CELLS = STEP / M;                 // QUAD: cells per chunk
-
-    __shared__ UnwrapShared<NP> s_u;
-    __shared__ double s_carry_v[N][NP];
-    __shared__ unsigned s_carry_state[N];
-    __shared__ double s_r[N][NV];
-    __shared__ double s_h[(MODE == MODE_QUAD) ? 2 * N : 1][SW_TX];
-
+// ---- mesh (OGG:488-518): one workgroup per row, chunks of SW_TX columns, exact unwrap -------------------------------
+__global__ __launch_bounds__(SW_TX) void dpole_mesh_kernel(SweepParams p) {
+    __shared__ UnwrapShared<1> s_u;
+    __shared__ double s_carry_v[1];
+    __shared__ unsigned s_carry_state;
     const int tid = threadIdx.x;
+    const long row = blockIdx.x;
     const DpConst c = dp_const(p);
-    const double reps = 1.0 / p.eps;
-    const long row = blockIdx.x;  // lattice row (MESH/EMIT) or band-local cell row (QUAD)
-    const long cell_row = (MODE == MODE_QUAD) ? (p.top_row ? p.ny : p.j0 + row) : 0;
-    const int n_kk = (MODE == MODE_QUAD) ? (p.top_row ? 1 : N) : 1;
-
-    // row-only quantities: gnomonic radius of the base row and of the rows displaced by +-m*eps (variant order:
-    // 0 = base, 2m-1 = +m*eps, 2m = -m*eps)
-    if (tid < N * NV) {
-        const int kk = tid / NV, var = tid % NV;
-        if (kk < n_kk) {
-            double jv;
-            if (MODE == MODE_QUAD)
-                jv = lattice_node(p.q, kk, cell_row);
-            else
-                jv = p.j_arr ? p.j_arr[row] : (double)(p.j0 + row);
-            if (var > 0) {
-                const double off = (double)((var + 1) / 2) * p.eps;
-                jv = (var & 1) ? jv + off : jv - off;
-            }
-            s_r[kk][var] = dp_row_radius(jv, p, c);
+    const double jv = p.j_arr ? p.j_arr[row] : (double)(p.j0 + row);
+    const double r = dp_row_radius(jv, p, c);                              // row-only
+    const double i_first = p.i_arr ? p.i_arr[0] : 0.0;
+    const double seed[1] = {p.lon0 + (i_first * 360.0) / (double)p.ni};    // lon_grid[0,0] (OGG:463)
+    for (long c0 = 0; c0 < p.n_cols; c0 += SW_TX) {
+        const long g = c0 + tid;
+        const bool active = g < p.n_cols;
+        double v[1] = {0.0}, ph = 0.0;
+        if (active) {
+            const double iv = p.i_arr ? p.i_arr[g] : (double)g;
+            dp_point(r, dp_column(iv, p, c), c, v[0], ph);
+        }
+        const unsigned st = unwrap_states<1>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
+        if (active && tid == SW_TX - 1) {
+            s_carry_v[0] = v[0];
+            s_carry_state = st;
+        }
+        if (active) {
+            p.out0[row * p.n_cols + g] = (st & 1u) ? v[0] - 360 : v[0];    // OGG:473
+            p.out1[row * p.n_cols + g] = ph;
         }
     }
-    // index of the first column of the row, for the seed lon_grid[0,0] (OGG:463)
-    double i_first;
-    if (MODE == MODE_QUAD)
-        i_first = lattice_node(p.q, 0, 0);
-    else
-        i_first = p.i_arr ? p.i_arr[0] : 0.0;
-    __syncthreads();
-
-    for (long c0 = 0; c0 < p.n_cols; c0 += STEP) {
-        if (MODE == MODE_QUAD && c0 > 0 && c0 + 1 >= p.n_cols) break;  // only the overlap column is left
-        const long g = c0 + tid;  // global column
-        const bool active = (g < p.n_cols) && (MODE != MODE_QUAD || tid <= STEP);
-        // column-only quantities for the NV column variants
-        cplx ep[NV];
-        if (active) {
-            double iv;
-            if (MODE == MODE_QUAD)
-                iv = lattice_node(p.q, (int)(g % M), g / M);
-            else
-                iv = p.i_arr ? p.i_arr[g] : (double)g;
-            ep[0] = dp_column(iv, p, c);
-#pragma unroll
-            for (int m = 1; m <= H; ++m) {
-                const double off = (double)m * p.eps;
-                ep[2 * m - 1] = dp_column(iv + off, p, c);
-                ep[2 * m] = dp_column(iv - off, p, c);
-            }
-        }
-        // last thread whose state/raw values seed the next chunk
-        const int carry_tid = (MODE == MODE_QUAD) ? STEP - 1 : SW_TX - 1;
-
-#pragma unroll 1
-        for (int kk = 0; kk < n_kk; ++kk) {
-            // probe order: [2(m-1)] = (j, i+m eps), [2(m-1)+1] = (j, i-m eps), then F + the same for (j+-m eps, i)
-            double v[NP], ph[NP];
-            if (active) {
-                if constexpr (MODE == MODE_MESH) {
-                    dp_point(s_r[kk][0], ep[0], c, v[0], ph[0]);
-                } else {
-#pragma unroll
-                    for (int m = 1; m <= H; ++m) {
-                        dp_point(s_r[kk][0], ep[2 * m - 1], c, v[2 * (m - 1)], ph[2 * (m - 1)]);
-                        dp_point(s_r[kk][0], ep[2 * m], c, v[2 * (m - 1) + 1], ph[2 * (m - 1) + 1]);
-                        dp_point(s_r[kk][2 * m - 1], ep[0], c, v[F + 2 * (m - 1)], ph[F + 2 * (m - 1)]);
-                        dp_point(s_r[kk][2 * m], ep[0], c, v[F + 2 * (m - 1) + 1], ph[F + 2 * (m - 1) + 1]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) v[q] = 0.0, ph[q] = 0.0;
-            }
-            double seed[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                // first column: compared with the seed lon_grid[0,0] (OGG:463), independent of any state
-                double di = 0.0;
-                if (MODE != MODE_MESH && q < F) {
-                    const double off = (double)(q / 2 + 1) * p.eps;
-                    di = (q & 1) ? -off : off;
-                }
-                seed[q] = p.lon0 + ((i_first + di) * 360.0) / (double)p.ni;
-            }
-            const unsigned st = unwrap_states<NP>(v, active, g == 0, seed, s_carry_v[kk], &s_carry_state[kk], s_u);
-
-            if (active && tid == carry_tid) {
-#pragma unroll
-                for (int q = 0; q < NP; ++q) s_carry_v[kk][q] = v[q];
-                s_carry_state[kk] = st;
-            }
-            // OGG:473: lower by 360 where flagged
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                if ((st >> q) & 1u) v[q] = v[q] - 360;
-
-            if constexpr (MODE == MODE_MESH) {
-                if (active) {
-                    p.out0[row * p.n_cols + g] = v[0];
-                    p.out1[row * p.n_cols + g] = ph[0];
-                }
-            } else {
-                double hi = 0.0, hj = 0.0;
-                if (active) {
-                    double dsi[HH], dsj[HH];
-#pragma unroll
-                    for (int m = 0; m < H; ++m) {
-                        dsi[m] = great_arc(v[2 * m], ph[2 * m], v[2 * m + 1], ph[2 * m + 1]);
-                        dsj[m] = great_arc(v[F + 2 * m], ph[F + 2 * m], v[F + 2 * m + 1], ph[F + 2 * m + 1]);
-                    }
-                    hi = central_difference<F>(dsi, reps);
-                    hj = central_difference<F>(dsj, reps);
-                }
-                if constexpr (MODE == MODE_EMIT) {
-                    if (active) {
-                        if (p.out0) p.out0[row * p.n_cols + g] = hi;
-                        if (p.out1) p.out1[row * p.n_cols + g] = hj;
-                    }
-                } else {
-                    s_h[2 * kk][tid] = hi;
-                    s_h[2 * kk + 1][tid] = hj;
-                }
-            }
-        }  // kk
-
-        if constexpr (MODE == MODE_QUAD) {
-            __syncthreads();
-            // one thread per cell of the chunk, reference summation order (OGG:593-595, 597-599)
-            const long ci = c0 / M + tid;
-            if (tid < CELLS && ci < p.nx) {
-                const int l0 = M * tid;
-                double yv[N];
-#pragma unroll
-                for (int ii = 0; ii < N; ++ii) yv[ii] = s_h[0][l0 + ii];
-                const long orow = p.top_row ? p.out_row : row;
-                p.out0[orow * p.nx + ci] = qavg_1d<N>(yv) * p.Re;
-                if (!p.top_row) {
-#pragma unroll
-                    for (int jj = 0; jj < N; ++jj) yv[jj] = s_h[2 * jj + 1][l0];
-                    p.out1[row * (p.nx + 1) + ci] = qavg_1d<N>(yv) * p.Re;
-                    if (ci == p.nx - 1) {
-#pragma unroll
-                        for (int jj = 0; jj < N; ++jj) yv[jj] = s_h[2 * jj + 1][l0 + M];
-                        p.out1[row * (p.nx + 1) + p.nx] = qavg_1d<N>(yv) * p.Re;
-                    }
-                    double da;
-                    if (N == 2) {
-                        const double d = 1.0 / 2.0;
-                        da = d * d * (s_h[0][l0] * s_h[1][l0] + s_h[0][l0 + 1] * s_h[1][l0 + 1] + s_h[2][l0] * s_h[3][l0] +
-                                      s_h[2][l0 + 1] * s_h[3][l0 + 1]);
-                    } else {
-                        const double w4[4] = {1.0, 5.0, 5.0, 1.0};
-                        const double d = 1.0 / 12.0;
-                        double ysum = 0.0;
-#pragma unroll
-                        for (int jj = 0; jj < N; ++jj)
-#pragma unroll
-                            for (int ii = 0; ii < N; ++ii)
-                                ysum = ysum + w4[ii & 3] * w4[jj & 3] * (s_h[2 * jj][l0 + ii] * s_h[2 * jj + 1][l0 + ii]);
-                        da = d * d * ysum;
-                    }
-                    p.out2[row * p.nx + ci] = da * p.Re * p.Re;
-                }
-            }
-            // the next chunk's first writes to s_h happen after two more barriers, which every thread passes only
-            // after it has finished the reads above
-        }
-    }  // chunks
 }
-
-
 
 // ---- finite-difference scale factors on a lattice row (OGG:535-562), one workgroup per lattice row and probe group ----
 // JGROUP = false: h_i from the 2H probes (j, i +- m eps);  JGROUP = true: h_j from the probes (j +- m eps, i).
@@ -688,10 +517,9 @@ __global__ __launch_bounds__(SW_TX) void dpole_direct_kernel(DirectParams p) {
     }
 }
 
-template <int F, int N, int MODE>
-int launch_sweep(const SweepParams& p, long blocks, hipStream_t s) {
+int launch_mesh(const SweepParams& p, long blocks, hipStream_t s) {
     if (blocks <= 0) return OGG_OK;
-    dpole_sweep_kernel<F, N, MODE><<<(unsigned)blocks, SW_TX, 0, s>>>(p);
+    dpole_mesh_kernel<<<(unsigned)blocks, SW_TX, 0, s>>>(p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }
@@ -711,10 +539,9 @@ int ogg_displaced_pole_mesh_dev(long n_i, const double* i, long n_j, const doubl
     OGG_REQUIRE(n_i > 0 && n_j >= 0 && i && j && lams && phis, OGG_EARG, "ogg_displaced_pole_mesh: bad argument");
     SweepParams p{};
     p.ni = ni, p.nj = nj, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lam_pole, p.r_pole = r_pole;
-    p.eps = 1.0, p.Re = 1.0;
-    p.n_cols = n_i, p.n_rows = n_j, p.i_arr = i, p.j_arr = j;
+    p.n_cols = n_i, p.i_arr = i, p.j_arr = j;
     p.out0 = lams, p.out1 = phis;
-    return launch_sweep<0, 1, MODE_MESH>(p, n_j, ogg::as_stream(stream));
+    return launch_mesh(p, n_j, ogg::as_stream(stream));
 }
 
 int ogg_displaced_pole_projection_dev(long nj, long ni, const double* lon_grid, const double* lat_grid, double z0_re,
@@ -743,10 +570,9 @@ int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, doub
                 "ogg_displaced_pole_grid: rows %ld..%ld outside 0..%ld", j0, j0 + nrows, Nj);
     SweepParams p{};
     p.ni = Ni, p.nj = Nj, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
-    p.eps = 1.0, p.Re = 1.0;
-    p.n_cols = Ni + 1, p.n_rows = nrows, p.i_arr = nullptr, p.j_arr = nullptr, p.j0 = j0;
+    p.n_cols = Ni + 1, p.i_arr = nullptr, p.j_arr = nullptr, p.j0 = j0;
     p.out0 = x, p.out1 = y;
-    return launch_sweep<0, 1, MODE_MESH>(p, nrows, ogg::as_stream(stream));
+    return launch_mesh(p, nrows, ogg::as_stream(stream));
 }
 
 int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, const double* j, long nx, long ny, double lon0,

@@ -398,3 +398,40 @@ def test_main_rejects_bad_flags(ogg):
         ogg.main(1.0, gridfilename=None, r_dp=0.2, lat_dp=-85.0)
     with pytest.raises(SystemExit):
         ogg.main(1.0, gridfilename=None, match_dy=["sc"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the literal kernels behind the default fast forms (selected by environment variables read at first use, hence a
+# fresh process): they must agree with the oracle at the same level, and with the default forms within their bounds
+# ---------------------------------------------------------------------------------------------------------------
+_LITERAL_SCRIPT = r"""
+import sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+from oracle import ogg_oracle as orc
+out = {}
+Ni, Nj, lat0 = 720, 120, 64.05895973
+rp = np.tan(0.5 * (90 - lat0) * orc.PI_180)
+got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
+want = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
+out["bp"] = [float(np.max(np.abs(g - w)[w != 0] / np.abs(w[w != 0]))) for g, w in zip(got, want)]
+got = ogg.displacedPoleCap_metrics_quad(4, 720, 70, -300.0, -78.0, 80.0, 0.2)
+want = orc.displacedPoleCap_metrics_quad(4, 720, 70, -300.0, -78.0, 80.0, 0.2)
+out["dp"] = [float(np.max(np.abs(g[36:] - w[36:]) / np.abs(w[36:]))) for g, w in zip(got, want)]
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"OGG_BP_GUARD_K": "0", "OGG_DP_LITERAL": "1"}])
+def test_literal_kernels_in_fresh_process(hip, env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", _LITERAL_SCRIPT % {"root": root}], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    record("literal_env_%d" % len(env), **{k: max(v) for k, v in res.items()})
+    assert max(res["bp"]) < 5e-14 and max(res["dp"]) < 5e-7
