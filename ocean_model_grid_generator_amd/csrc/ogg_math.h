@@ -79,6 +79,13 @@ OGG_DEV double rcp_nr(double x) {
     return fma(y, e, y);
 }
 
+OGG_DEV double rsqrt_nr(double x) {  // 1/sqrt(x), normal positive x
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    return y * fma(-hx * y, y, 1.5);
+}
+
 OGG_DEV double sqrt_nr(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
