@@ -155,7 +155,8 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("OGG_FORCE_DIST"))   # OGG_FORCE_DIST: exercise the RCCL calls at world size 1
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device(device))
 
     from ocean_model_grid_generator_amd import _lib, supergrid
@@ -171,7 +172,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -191,7 +192,7 @@ def main():
             sg.run_pass()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -247,7 +248,7 @@ def main():
                                              "workload: %d cells in %.1f s" % (args.cpu_sample_div, cells, cdt),
                                    "host_cpus": os.cpu_count()}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
