@@ -2,20 +2,21 @@
 
 One process per GPU.  Every rank owns a contiguous band of rows of EACH sub-grid (southern cap, Southern Ocean,
 Mercator, bipolar cap): cost per row differs by ~100x between the lat-lon sub-grids and the caps, so cutting the
-stitched grid into contiguous slabs would not balance.  One pass =
+stitched grid into contiguous slabs would not balance.  One pass (default pipeline, ``latlon="fused"``) is
 
-  phase A  coordinates   1-D axes (every rank, a few thousand values), lat-lon tiles, bipolar mesh,
-                         displaced-pole mesh                                                   [K1, K3, K5]
-  halo                   the first x/y row of the band above -> the extra row of this band, for the sub-grids whose
-                         metrics use the (j, j+1) stencil; neighbour send/recv over RCCL (torch.distributed "nccl")
-  phase B  metrics       fused MIDAS dx/dy/area + angle_dx; bipolar and displaced-pole quadratures; angle_dx of the
-                         caps                                                                  [K2, K4, K6]
+  main stream     one launch for all lat-lon bands (Mercator, Southern Ocean, regular southern cap): x, y, dx, dy, area,
+                  angle_dx from the axis formulas, 48 B written per cell, nothing read
+  side streams    bipolar mesh + angle | bipolar quadrature | displaced-pole mesh + angle | displaced-pole quadrature
 
-The caps need no exchange (their metrics are analytic in (i, j); the displaced-pole unwrap runs along i inside a
-row).  All six fields of every band stay in HBM (torch tensors); `gather()` copies them out and stitches on the host
-exactly as the reference does (OGG:1315-1365).
+with no exchange between ranks: the caps are analytic in (i, j) and the lat-lon kernel needs only the axis formulas.
+``latlon="stencil"`` is the pipeline of BASELINE.json's north_star taken literally: tile x, y (K1); send the first x/y row of
+every band to the rank below (neighbour send/recv over RCCL, torch.distributed backend "nccl"); generic 2x3-stencil kernel
+(K2) that reads x, y back.  Both give the same bits.
 
-torch is used for device memory, streams and torch.distributed only; every number is produced by libogg_hip.so.
+All six fields of every band stay in HBM (torch tensors); ``bands_to_host()`` copies them out and ``stitch()`` assembles the
+sub-grids on the host exactly as the reference does (OGG:1315-1365).
+
+torch is used for device memory, streams, graphs and torch.distributed only; every number is produced by libogg_hip.so.
 """
 import math
 
