@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--as-world", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="run the caps on side streams next to the lat-lon sub-grids")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
+                    help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
+                         "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
     args = ap.parse_args()
 
     import torch
@@ -176,9 +179,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    can_graph = not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
+    use_graph = bool(args.graph) and can_graph
+    tuned = None
+    if args.latlon == "fused" and args.launch == "auto":
+        # set-up, untimed: every rank keeps the launch scheme that is fastest for ITS share (there is no collective in a pass)
+        tuned = {}
+        for launch, overlap, graph in (("pass", 0, 0), ("pass", 0, 1), ("kernels", 1, 1), ("kernels", 0, 0)):
+            sg.launch, sg.overlap = launch, bool(overlap)
+            if graph and not can_graph:
+                continue
+            for _ in range(2):
+                sg.step()
+            if graph:
+                sg.capture()
+                sg.replay()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(10):
+                sg.replay() if graph else sg.run_pass()
+            torch.cuda.synchronize()
+            tuned["%s overlap=%d graph=%d" % (launch, overlap, graph)] = (time.perf_counter() - ta) / 10 * 1e3
+        best = min(tuned, key=tuned.get)
+        launch, overlap, graph = best.split()
+        sg.launch, sg.overlap, use_graph = launch, overlap.endswith("1"), graph.endswith("1")
+    elif args.latlon == "fused":
+        sg.launch = args.launch
     for _ in range(args.warmup):
         sg.step()
-    use_graph = bool(args.graph) and not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
     if use_graph:
         sg.capture()
         sg.replay()  # one untimed replay
@@ -198,7 +226,10 @@ def main():
         dt = float(t.item())
     # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
     # stream (events cannot be read back from inside a replayed graph)
+    timed_launch = "%s%s%s" % (sg.launch, ", caps on side streams" if (sg.launch == "kernels" and sg.overlap) else "",
+                               ", hip graph replay" if use_graph else ", eager")
     sg._events = {}
+    sg.launch = "kernels"
     sg.overlap = False  # kernels one after the other on one stream: undisturbed per-kernel durations
     t1 = time.perf_counter()
     for _ in range(args.steps):
@@ -232,7 +263,7 @@ def main():
                        "flags": flags, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
                        "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
                            world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
-            "device": _lib.device_name(), "launch": "hip graph replay" if use_graph else "eager",
+            "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned,
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -162,6 +162,28 @@ int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0
                                         long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
                                         void* workspace, long workspace_bytes, void* stream);
 
+/* One rank's share of a tripolar supergrid -- the lat-lon sub-grids and the bipolar cap generated by the sub-grid loop of
+ * main() (OGG:1100-1313: generate_mercator_grid / generate_latlon_grid / generate_bipolar_cap_mesh + angle_x +
+ * bipolar_cap_metrics_quad_fast) -- in three launches on one stream: the HBM-bound lat-lon row strips and the VALU-bound
+ * cap workgroups share each launch, so nothing waits on a cross-stream dependency.  Results are bit-identical to
+ * ogg_latlon_supergrid_multi_dev + ogg_bipolar_cap_mesh_angle_dev + ogg_bipolar_cap_metrics_quad_ws_dev on the same bands.
+ * cap may be NULL (no cap rows on this rank); metrics == 0 writes coordinates and angle_dx only. */
+typedef struct ogg_bipolar_band {
+    long Ni, Nj;             /* the cap is (Nj+1) x (Ni+1) points */
+    double lat0_bp, lon_bp;  /* OGG:103 */
+    double rp, Re;           /* OGG:117; sphere radius */
+    int order;               /* Gauss-Lobatto order of the quadrature, 2..5 (OGG:191-204) */
+    long j0;                 /* first mesh row of the band */
+    long n_pt_rows;          /* point rows: x, y, angle (n_pt_rows x (Ni+1)), dx (n_pt_rows x Ni) */
+    long n_cell_rows;        /* cell rows: dy (n_cell_rows x (Ni+1)), area (n_cell_rows x Ni); n_pt_rows - 1 on the band that
+                                holds row Nj, else n_pt_rows */
+    double *x, *y, *angle, *dx, *dy, *area;
+    void* workspace;         /* >= ogg_bipolar_quad_workspace_bytes(order, Ni, Nj) bytes of device memory (metrics only) */
+    long workspace_bytes;
+} ogg_bipolar_band;
+int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
+                          int metrics, const ogg_bipolar_band* cap, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Displaced-pole Southern cap
  * ---------------------------------------------------------------------------------------------------- */

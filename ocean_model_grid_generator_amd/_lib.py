@@ -24,6 +24,14 @@ class LatlonBand(ctypes.Structure):
                 ("y", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p), ("angle", c_void_p)]
 
 
+class BipolarBand(ctypes.Structure):
+    """ogg_bipolar_band of include/ogg_hip.h"""
+    _fields_ = [("Ni", c_long), ("Nj", c_long), ("lat0_bp", c_double), ("lon_bp", c_double), ("rp", c_double), ("Re", c_double),
+                ("order", c_int), ("j0", c_long), ("n_pt_rows", c_long), ("n_cell_rows", c_long), ("x", c_void_p), ("y", c_void_p),
+                ("angle", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p), ("workspace", c_void_p),
+                ("workspace_bytes", c_long)]
+
+
 # name -> argtypes; every function returns int except the two string getters.  Must list EVERY symbol of ogg_hip.h
 # (tests/test_abi.py checks this list against the header).
 SIGNATURES = {
@@ -92,6 +100,8 @@ SIGNATURES = {
     "ogg_monotonic_bounding": [c_long, c_long, c_void_p, c_double],
     "ogg_monotonic_bounding_dev": [c_long, c_long, c_void_p, c_double, c_void_p],
     "ogg_latlon_supergrid_multi_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int, c_void_p],
+    "ogg_tripolar_pass_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
+                              ctypes.POINTER(BipolarBand), c_void_p],
     "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],

@@ -1,0 +1,703 @@
+// K3 / K4: Murray bipolar Arctic cap -- device code (included by ogg_bipolar.hip and by the fused pass, ogg_pass.hip).
+//   bipolar_projection                 OGG:33-100   (element-wise kernel + the mesh builder OGG:103-122)
+//   bipolar_cap_metrics_quad_fast      OGG:136-188  (+ bipolar_cap_ij_array OGG:125-133, quadrature OGG:191-255)
+//
+// K4 is fp64-VALU bound (an acos, a tan, an atan, a cos and two sqrt per lattice point; 24 B written per cell).
+// The projection is split into its row-only part (5 libm calls per lattice row), its column-only part (sincos + fmod
+// per lattice column) -- both tabulated once per call -- and the per-point remainder.  Lobatto nodes on shared cell
+// edges are bit-identical in the reference (node n-1 of cell k == node 0 of cell k+1 == k+1 exactly), so a wave that walks
+// a strip of cells evaluates every unique lattice point once -- (n-1)^2 instead of n^2 evaluations per cell -- and
+// exchanges edge values by wave shuffles; sums follow the reference's order (OGG:216-221, 246-253).  The full lattice
+// (138 M points at 1/8 degree) is never materialised.
+#pragma once
+#include <cstdlib>
+
+#include "ogg_common.h"
+#include "ogg_math.h"
+
+namespace {
+
+using namespace ogg;
+
+// ---- pieces of OGG:41-95 ------------------------------------------------------------------------------
+struct BpRow {       // depends on the (fractional) row index only
+    double sphig;     // sin(phig*PI_180)                      OGG:44
+    double beta2_inv; // tan(phig*PI_180)^2                    OGG:46
+    double N_inv;     // OGG:75-78
+};
+struct BpCol {       // depends on the (fractional) column index only
+    double sinla;     // OGG:43
+    double alpha2;    // OGG:45
+};
+
+OGG_DEV BpRow bp_row(double phig_in, double rp) {
+    BpRow r;
+    const double phig = 90 - 2 * atan(tan(0.5 * (90 - phig_in) * kPi180) / rp) / kPi180;  // OGG:41
+    const double pr = phig * kPi180;
+    r.sphig = sin(pr);
+    const double t = tan(pr);
+    r.beta2_inv = t * t;
+    const double chig = (90 - phig) * kPi180;
+    const double tg = tan(chig / 2);
+    const double rden2 = 1.0 / (1 + (rp * tg) * (rp * tg));
+    const double N = rp * (1 + tg * tg) * rden2;
+    r.N_inv = 1 / N;
+    return r;
+}
+
+OGG_DEV BpCol bp_col(double lamg, double lon_bp) {
+    BpCol c;
+    const double tmp = mdist(lamg, lon_bp) * kPi180;  // OGG:42
+    double s, co;
+    sincos(tmp, &s, &co);
+    c.sinla = s;
+    c.alpha2 = co * co;
+    return c;
+}
+
+// per-point remainder: phis (OGG:68-70) and the inverse scale factors (OGG:72-95)
+OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, double& h_i_inv, double& h_j_inv, double& rden_out) {
+    const double rden = 1.0 / (1.0 + c.alpha2 * r.beta2_inv);  // OGG:47
+    const double A = c.sinla * r.sphig;
+    const double chic = acos(A);
+    const double t = tan(chic / 2);
+    const double rpt = rp * t;
+    phis = 90 - 2 * atan(rpt) / kPi180;
+    const double rden2 = 1.0 / (1 + rpt * rpt);
+    const double M_inv = rp * (1 + t * t) * rden2;
+    const double cp = cos(phis * kPi180);
+    const double cos2phis = cp * cp;
+    const double MM = M_inv * M_inv;
+    const bool huge = fabs(r.beta2_inv) > kHuge;
+    const double rr = rden * rden;
+    double hj = cos2phis * c.alpha2 * (1 - c.alpha2) * r.beta2_inv * (1 + r.beta2_inv) * rr + MM * (1 - c.alpha2) * rden;
+    if (huge) hj = MM;
+    h_j_inv = sqrt(hj) * r.N_inv;
+    double hi = cos2phis * (1 + r.beta2_inv) * rr + MM * c.alpha2 * r.beta2_inv * rden;
+    if (huge) hi = MM;
+    h_i_inv = sqrt(hi);
+    rden_out = rden;
+}
+
+// Algebraically reduced form of bp_point for the quadrature lattice (metrics only).  With A = sinla*sphig in [0,1]:
+//   tan(acos(A)/2)^2 = (1-A)/(1+A),   1 + (rp t)^2 = D/(1+A),  D = (1+A) + rp^2 (1-A)
+//   M_inv = rp (1+t^2) / (1+(rp t)^2) = 2 rp / D
+//   cos^2(phis PI/180) = sin^2(2 atan(rp t)) = 4 rp^2 (1-A)(1+A) / D^2
+// so the acos -> tan -> atan -> cos round trip of OGG:69-79 collapses to one division (returns the SQUARES of h_i_inv and
+// of h_j_inv*N; the caller takes the roots and applies the per-index scale factors of OGG:131-132 as multiplications).  The identities are exact; the
+// results differ from the literal sequence only by rounding: <= 1e-14 relative where the cap latitude is >= 1.4 degrees
+// from the pole (measured against the oracle on the 1/8 degree lattice; 4e-15 at >= 4 degrees).  Nearer the pole the
+// LITERAL sequence loses digits (phis = 90 - small is rounded to 1 ulp of 90 before the cosine), and parity with the
+// reference means reproducing that: every point carries a guard (below) and the cells with a guarded point are
+// re-evaluated with bp_point by a fix-up kernel (about 0.4 % of the cells at 1/8 degree, around the two pole points).
+template <bool GUARD>
+OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
+                           double guard_k, double& hi2, double& hj2) {
+    // bb1 = b (1+b) is row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them
+    const double a = c.alpha2, b = r.beta2_inv;
+    const double ab = a * b;
+    const double A = c.sinla * r.sphig;
+    const double p1 = 1 + A, m1 = 1 - A;
+    const double P = 1.0 + ab;                    // 1/rden
+    const double D = p1 + rp2 * m1;
+    const double inv = rcp_nr(P * D);             // one reciprocal for both quotients
+    const double rden = D * inv, E = P * inv;
+    const double MM = rp2x4 * (E * E);            // M_inv^2
+    const double cc = MM * (m1 * p1);             // cos^2(phis) = sin^2(2 atan(rp t))
+    const double ccrr = cc * (rden * rden);
+    const double Mr = MM * rden;
+    const double t1j = ccrr * (aa1 * bb1), t1i = ccrr * (1 + b);
+    hj2 = t1j + Mr * a1;
+    hi2 = t1i + Mr * ab;
+    // (the |beta2_inv| > HUGE case of OGG:86,94 only occurs on the exact j = ny row, which never takes this path)
+    //
+    // Exactness guard.  The literal sequence rounds phis = 90 - 2 atan(rp t)/PI_180 to a multiple of ulp(90) before taking
+    // its cosine, which perturbs cos^2(phis) by up to 2.4e-16 / atan(rp t) relative; the algebraic value does not have that
+    // perturbation, so where the cos^2 term carries weight w in h^2 the two differ by ~ w * 1.2e-16 / atan(rp t) in h.
+    // With atan(u) >= u/(1+u^2) = sqrt(cc)/2 the point is handed to the literal fix-up when w^2 > K * cc, i.e. when the
+    // difference could exceed ~ 2.4e-16 / sqrt(K) * ... (K = 1000: measured worst unflagged difference 8e-15 at 1/8 degree).
+    // Since w <= 1 a point can only be guarded where cos^2(phis) < 1/K, i.e. (phis <= grid latitude of the row) on the
+    // lattice rows with cos^2(lat) < 1/K: the rows below that latitude run the GUARD = false instantiation.
+    if (!GUARD) return false;
+    const double gi = t1i * t1i, gj = t1j * t1j;
+    const double kc = guard_k * cc;
+    return (gi > kc * (hi2 * hi2)) || (gj > kc * (hj2 * hj2));
+}
+
+// lams of OGG:50-64
+OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double rden, double lamg, double lon_bp) {
+    double B = c.sinla * sqrt(rden);
+    if (fabs(r.beta2_inv) > kHuge) B = 0.0;
+    double lamc = asin(B) / kPi180;
+    const double dl = lamg - lon_bp;
+    if ((dl > 90) && (dl <= 180)) lamc = 180 - lamc;
+    if ((dl > 180) && (dl <= 270)) lamc = 180 + lamc;
+    if (dl > 270) lamc = 360 - lamc;
+    if (dl == 90) lamc = 90;
+    if (dl == 270) lamc = 270;
+    return lamc + lon_bp;
+}
+
+// ---- element-wise projection on arbitrary inputs ---------------------------------------------------------
+__global__ void bipolar_projection_kernel(long n, const double* __restrict__ lamg, const double* __restrict__ phig,
+                                          double lon_bp, double rp, double* __restrict__ lams, double* __restrict__ phis,
+                                          double* __restrict__ hi, double* __restrict__ hj) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double lg = lamg[k];
+    const BpRow r = bp_row(phig[k], rp);
+    const BpCol c = bp_col(lg, lon_bp);
+    double ps, h_i, h_j, rden;
+    bp_point(r, c, rp, ps, h_i, h_j, rden);
+    if (lams) lams[k] = bp_lams(r, c, rden, lg, lon_bp);
+    if (phis) phis[k] = ps;
+    if (hi) hi[k] = h_i;
+    if (hj) hj[k] = h_j;
+}
+
+// ---- mesh builder (OGG:103-122) fused with angle_x (OGG:719-729), rows j0 .. j0+nrows-1 ------------------------
+// A wave owns 62 output columns plus one halo column on either side, so the i-1 / i+1 neighbours that angle_x needs
+// come from wave shuffles and every lane does the same work.  Row-only factors are computed once per row of the
+// workgroup (LDS), column-only factors once per lane.  For the coordinates, tan(acos(A)/2) is evaluated as
+// sqrt((1-A)/(1+A)) (exact identity; phis then differs from the literal sequence by at most 1 ulp of 90 degrees, 1.4e-14);
+// the scale factors, when requested, follow the literal sequence (bp_point).
+constexpr int MESH_WAVES = 4;
+constexpr int MESH_OUT = 62;   // output columns per wave
+constexpr int MESH_ROWS = 8;   // rows per workgroup (OGG_MESH_ROWS: fewer, for experiments)
+
+struct MeshParams {
+    long Ni, Nj;
+    double lat0_bp, lon_bp;
+    long j0, nrows;
+    double *lams, *phis, *hi, *hj, *angle;
+    int rows_per_wg;   // 1..MESH_ROWS
+};
+
+// workgroup (bx, by) of the mesh grid; s_row: MESH_ROWS entries of LDS
+OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long by) {
+    const long Ni = m.Ni, Nj = m.Nj, j0 = m.j0, nrows = m.nrows;
+    const double lat0_bp = m.lat0_bp, lon_bp = m.lon_bp;
+    double* __restrict__ lams = m.lams;
+    double* __restrict__ phis = m.phis;
+    double* __restrict__ hi = m.hi;
+    double* __restrict__ hj = m.hj;
+    double* __restrict__ angle = m.angle;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long jl0 = by * m.rows_per_wg;
+    const int nr = (int)((nrows - jl0 < m.rows_per_wg) ? (nrows - jl0) : m.rows_per_wg);
+    const double rp = tan(0.5 * (90 - lat0_bp) * kPi180);                              // OGG:117
+    if (tid < nr) {
+        const long j = j0 + jl0 + tid;
+        const double phig = lat0_bp + ((double)j * (90 - lat0_bp)) / (double)Nj;       // OGG:115
+        s_row[tid] = bp_row(phig, rp);
+    }
+    __syncthreads();
+    const long col0 = (bx * MESH_WAVES + wave) * MESH_OUT;  // first output column of this wave
+    if (col0 > Ni) return;                                                // wave-uniform
+    long i = col0 - 1 + lane;
+    i = i < 0 ? 0 : (i > Ni ? Ni : i);                                    // halo lanes beyond the row ends are clamped
+    const bool out = (lane >= 1) && (lane <= MESH_OUT) && (col0 - 1 + lane <= Ni);
+    const double lamg = lon_bp + ((double)i * 360.0) / (double)Ni;                     // OGG:113
+    const BpCol c = bp_col(lamg, lon_bp);
+    const long ni1 = Ni + 1;
+    for (int r = 0; r < nr; ++r) {
+        const BpRow row = s_row[r];
+        const long jl = jl0 + r, j = j0 + jl;
+        const double rden = 1.0 / (1.0 + c.alpha2 * row.beta2_inv);                    // OGG:47
+        const double lam = bp_lams(row, c, rden, lamg, lon_bp);
+        const double A = c.sinla * row.sphig;
+        const double t = sqrt((1 - A) / (1 + A));                                      // == tan(acos(A)/2), OGG:69-70
+        const double phi = 90 - 2 * atan(rp * t) / kPi180;
+        if (out) {
+            lams[jl * ni1 + i] = lam;
+            phis[jl * ni1 + i] = phi;
+        }
+        if (hi || hj) {
+            double ps, h_i, h_j, rd;
+            bp_point(row, c, rp, ps, h_i, h_j, rd);
+            if (out && hi && i < Ni) hi[jl * Ni + i] = h_i * 2 * kPi / (double)Ni;                    // OGG:119
+            if (out && hj && j < Nj) hj[jl * ni1 + i] = h_j * kPi180 * (90 - lat0_bp) / (double)Nj;   // OGG:120
+        }
+        if (angle) {                                                                   // OGG:725-728
+            const double xl = __shfl_up(lam, 1), xr = __shfl_down(lam, 1);
+            const double yl = __shfl_up(phi, 1), yr = __shfl_down(phi, 1);
+            const double cy = cos(phi * kPi180);
+            double a;
+            if (i == 0)
+                a = atan2(yr - phi, (xr - lam) * cy);
+            else if (i == Ni)
+                a = atan2(phi - yl, (lam - xl) * cy);
+            else
+                a = atan2(yr - yl, (xr - xl) * cy);
+            if (out) angle[jl * ni1 + i] = a / kPi180;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * MESH_WAVES) void bipolar_mesh_kernel(MeshParams m) {
+    __shared__ BpRow s_row[MESH_ROWS];
+    bipolar_mesh_body(m, s_row, blockIdx.x, blockIdx.y);
+}
+
+// sets m.rows_per_wg.  The column-only factors (sincos + two fmod) cost about as much as half a point, so a wave keeps
+// MESH_ROWS rows even when the band is small: fewer rows per workgroup measured slower down to 1/8 of the 1/8 degree cap.
+inline dim3 mesh_grid(MeshParams& m) {
+    const long n_waves = (m.Ni + 1 + MESH_OUT - 1) / MESH_OUT;
+    const long gx = (n_waves + MESH_WAVES - 1) / MESH_WAVES;
+    long rpw = MESH_ROWS;
+    if (const char* e = getenv("OGG_MESH_ROWS")) rpw = atol(e) < 1 ? 1 : (atol(e) > MESH_ROWS ? MESH_ROWS : atol(e));
+    m.rows_per_wg = (int)rpw;
+    return dim3((unsigned)gx, (unsigned)((m.nrows + rpw - 1) / rpw));
+}
+
+// ---- quadrature metrics -------------------------------------------------------------------------------------
+struct QuadParams {
+    long nx, ny;
+    double lat0_bp, lon_bp, rp, Re;
+    long j0;           // first cell row of the band (band-local output row 0)
+    double guard_k;       // exactness guard of bp_point_fast
+    unsigned* fix_count;  // number of cells handed to the literal fix-up ...
+    unsigned* fix_list;   // ... and their band-local linear indices out_r*nx + ci
+    const BpRow* row_tab;  // [(N-1)*ny + 2]: unique lattice rows; entry (N-1)*ny is the ny-0.001 row, the last one is j = ny exactly
+    const BpCol* col_tab;  // [(N-1)*nx + 1]: unique lattice columns
+    double* dxq;
+    double* dyq;
+    double* daq;
+    QuadNodes q;
+};
+
+struct QuadRange {     // the part of the band one grid of strip workgroups evaluates
+    long row_begin;    // cell rows [row_begin, row_end)
+    long row_end;
+    long rows_per_chunk;  // cell rows one wave walks (its first lattice row is recomputed: 1/((N-1)*rows_per_chunk) extra)
+    int top_row;       // 1: evaluate only dxq[ny][:] (exact j = ny lattice row) into band row out_row; 2: same, computing the
+                       //    row / column factors instead of reading the tables
+    long out_row;
+    unsigned gy;       // workgroups along the rows
+};
+
+// row-only and column-only parts of the projection for every unique lattice row / column of the cap (OGG:126-127,
+// 41-46, 75-78), evaluated once per call instead of once per tile
+template <int N>
+OGG_DEV void bipolar_tables_body(const QuadParams& p, long bx) {
+    constexpr int M = N - 1;
+    BpRow* row_tab = const_cast<BpRow*>(p.row_tab);
+    BpCol* col_tab = const_cast<BpCol*>(p.col_tab);
+    const long k = bx * blockDim.x + threadIdx.x;
+    const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
+    if (k == 0) *p.fix_count = 0u;  // the fix-up list of this call starts empty (this kernel precedes the quadrature kernels)
+    if (k < n_rows) {
+        double jv;
+        if (k == M * p.ny)
+            jv = (double)p.ny - 0.001;  // OGG:146-147: last node of cell ny-1
+        else if (k == M * p.ny + 1)
+            jv = lattice_node(p.q, 0, p.ny);  // first node of cell ny: j = ny exactly (feeds dxq[ny])
+        else
+            jv = lattice_node(p.q, (int)(k % M), k / M);
+        const double latg = p.lat0_bp + (jv * (90 - p.lat0_bp)) / (double)p.ny;   // OGG:127
+        row_tab[k] = bp_row(latg, p.rp);
+    } else if (k < n_rows + n_cols) {
+        const long u = k - n_rows;
+        const double iv = lattice_node(p.q, (int)(u % M), u / M);
+        const double lon = p.lon_bp + (iv * 360.0) / (double)p.nx;               // OGG:126
+        col_tab[u] = bp_col(lon, p.lon_bp);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void bipolar_tables_kernel(QuadParams p) {
+    bipolar_tables_body<N>(p, blockIdx.x);
+}
+
+template <int N>
+inline unsigned tables_blocks(const QuadParams& p) {
+    return (unsigned)(((N - 1) * p.ny + 2 + (N - 1) * p.nx + 1 + 255) / 256);
+}
+
+template <int N>
+OGG_DEV double quad_average_1d(const double* y) {  // OGG:207-222
+    if (N == 2) return (1.0 / 2.0) * (y[0] + y[1]);
+    if (N == 3) return (1.0 / 6.0) * (4.0 * y[1] + (y[0] + y[2]));
+    if (N == 4) return (1.0 / 12.0) * (5.0 * (y[1] + y[2]) + (y[0] + y[3]));
+    return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
+}
+
+template <int N>
+OGG_DEV double quad_weight_1d(int k) {  // w[k] of OGG:240 / 248, as selects (k may be a run-time value)
+    if (N == 4) return (k == 0 || k == 3) ? 1.0 : 5.0;
+    return (k == 0 || k == 4) ? 9.0 : ((k == 2) ? 64.0 : 49.0);
+}
+
+// A wave owns a vertical strip of 63 cells (lane 63 is a halo lane: the first cell of the next strip) and walks up the
+// cell rows of its chunk.  Each lane evaluates the (N-1) x (N-1) lattice points of its cell that are not on the cell's
+// right or top edge; the right-edge values are the left-edge values of lane+1 (one wave shuffle), the top-edge row is the
+// bottom row of the next cell row and is evaluated once and reused.  So every unique lattice point of the strip is
+// evaluated exactly once -- (N-1)^2 instead of N^2 evaluations per cell -- with no LDS and no barrier; the row-only
+// factors are wave-uniform (scalar loads), the column-only factors stay in registers for the whole walk.  Sums are taken
+// in the reference's order (OGG:216-221, 244-253).
+constexpr int QS_CELLS = 63;   // cells per wave strip
+constexpr int QS_WAVES = 4;    // strips per workgroup
+
+template <int N, int MODE>
+struct RowEval {
+    double dx[N];  // dx at this lane's columns ii = 0..N-2 and, in [N-1], at the right edge (from lane+1)
+    double dy[N];
+    int guarded;   // any of these N points failed the exactness guard (always 0 on the literal path)
+};
+
+constexpr int QM_FAST = 0, QM_GUARD = 1, QM_LITERAL = 2;  // per-point method of the strip kernel
+
+template <int N, int MODE>
+OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* col, double sx, double sy, double rp2x4, double rp2,
+                              RowEval<N, MODE>& o) {  // r: factors of the lattice row (wave-uniform)
+    constexpr int M = N - 1;
+    constexpr bool FAITHFUL = (MODE == QM_LITERAL);
+    if (FAITHFUL) {
+        // one point at a time (the libm calls of several points interleaved cost 225 VGPRs = 2 waves/SIMD); the column
+        // entry and the result slot are picked with compare-selects so that no register array is indexed dynamically
+#pragma unroll 1
+        for (int ii = 0; ii < M; ++ii) {
+            BpCol c = col[0];
+#pragma unroll
+            for (int k = 1; k < M; ++k) {
+                c.sinla = (ii == k) ? col[k].sinla : c.sinla;
+                c.alpha2 = (ii == k) ? col[k].alpha2 : c.alpha2;
+            }
+            double phis, rden, h_i, h_j;
+            bp_point(r, c, p.rp, phis, h_i, h_j, rden);
+            const double dx = h_i * 2 * kPi / (double)p.nx;                        // OGG:131
+            const double dy = h_j * (90 - p.lat0_bp) * kPi180 / (double)p.ny;      // OGG:132
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                o.dx[k] = (ii == k) ? dx : o.dx[k];
+                o.dy[k] = (ii == k) ? dy : o.dy[k];
+            }
+        }
+    } else {
+        const double bb1 = r.beta2_inv * (1 + r.beta2_inv), nsy = r.N_inv * sy;
+        int g_first = 0, g_any = 0;
+#pragma unroll
+        for (int ii = 0; ii < M; ++ii) {
+            double hi2, hj2;
+            const double a1 = 1 - col[ii].alpha2;
+            const bool g = bp_point_fast<MODE == QM_GUARD>(r, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, p.guard_k, hi2, hj2);
+            if (ii == 0) g_first = g;
+            g_any |= (int)g;
+            o.dx[ii] = sqrt_nr(hi2) * sx;
+            // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): sqrt_nr(0) would be 0 * inf
+            o.dy[ii] = (hj2 > 0.0) ? sqrt_nr(hj2) * nsy : 0.0;
+        }
+        o.guarded = 0;
+        if (MODE == QM_GUARD) o.guarded = g_any | __shfl_down(g_first, 1);  // the right edge is lane+1's first column
+    }
+    if (FAITHFUL) o.guarded = 0;
+    o.dx[M] = __shfl_down(o.dx[0], 1);
+    o.dy[M] = __shfl_down(o.dy[0], 1);
+}
+
+template <int N, int MODE>
+OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long bx, long by) {
+    constexpr int M = N - 1;
+    constexpr bool FAITHFUL = (MODE == QM_LITERAL);
+    const int lane = threadIdx.x & 63;
+    const long strip = bx * QS_WAVES + (threadIdx.x >> 6);
+    if (strip * QS_CELLS >= p.nx) return;  // wave-uniform
+    const long ci = strip * QS_CELLS + lane;
+    const long n_cols_tab = M * p.nx + 1;
+    BpCol col[M];
+#pragma unroll
+    for (int ii = 0; ii < M; ++ii) {
+        long u = M * ci + ii;
+        if (u > n_cols_tab - 1) u = n_cols_tab - 1;
+        if (rg.top_row == 2) {  // tables not available yet (same launch): the expressions of bipolar_tables_body
+            const double iv = lattice_node(p.q, (int)(u % M), u / M);
+            col[ii] = bp_col(p.lon_bp + (iv * 360.0) / (double)p.nx, p.lon_bp);
+        } else {
+            col[ii] = p.col_tab[u];
+        }
+    }
+    const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
+    const double sx = (2 * kPi) / (double)p.nx, sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
+    const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
+    RowEval<N, MODE> cur;
+    if (rg.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
+        BpRow rt;
+        if (rg.top_row == 2)
+            rt = bp_row(p.lat0_bp + (lattice_node(p.q, 0, p.ny) * (90 - p.lat0_bp)) / (double)p.ny, p.rp);
+        else
+            rt = p.row_tab[(long)M * p.ny + 1];
+        eval_lattice_row<N, MODE>(p, rt, col, sx, sy, rp2x4, rp2, cur);
+        if (cell_lane) p.dxq[rg.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
+        return;
+    }
+    const long r0 = rg.row_begin + by * rg.rows_per_chunk;
+    const long r1 = (r0 + rg.rows_per_chunk < rg.row_end) ? r0 + rg.rows_per_chunk : rg.row_end;
+    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, sx, sy, rp2x4, rp2, cur);
+    for (long c = r0; c < r1; ++c) {
+        const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
+        int guarded = cur.guarded;                                          // bottom-edge row (carried)
+        double dyc[N];                                                      // dy down this lane's left edge
+        double y2[(N <= 3) ? N * N : 1];
+        double ysum = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) dyc[k] = 0.0;
+#pragma unroll(N <= 3 ? N : 1)
+        for (int jj = 0; jj < N; ++jj) {
+            if (jj > 0) {
+                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, sx, sy, rp2x4, rp2, cur);
+                guarded |= cur.guarded;
+            }
+            const double wj = quad_weight_1d<N>(jj);
+#pragma unroll
+            for (int ii = 0; ii < N; ++ii) {
+                const double pr = cur.dx[ii] * cur.dy[ii];                  // OGG:178
+                if (N <= 3) {
+#pragma unroll
+                    for (int k = 0; k < N * N; ++k)
+                        if (N <= 3 && k == jj * N + ii) y2[(N <= 3) ? k : 0] = pr;
+                } else {
+                    ysum = ysum + (quad_weight_1d<N>(ii) * wj) * pr;        // OGG:244 / 252
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) dyc[k] = (jj == k) ? cur.dy[0] : dyc[k];
+        }
+        // cur now holds lattice row (c, N-1) == (c+1, 0): the bottom row of the next cell row
+        const long out_r = c - p.j0;
+        if (ci == p.nx) p.dyq[out_r * (p.nx + 1) + p.nx] = quad_average_1d<N>(dyc) * p.Re;  // first node column of cell nx
+        if (cell_lane) {
+            p.dxq[out_r * p.nx + ci] = dxq;
+            p.dyq[out_r * (p.nx + 1) + ci] = quad_average_1d<N>(dyc) * p.Re;                  // OGG:184,187
+            double da;
+            if (N == 2) {
+                const double d = 1.0 / 2.0;
+                da = d * d * (y2[0] + y2[1] + y2[(N <= 3) ? N : 0] + y2[(N <= 3) ? N + 1 : 0]);
+            } else if (N == 3) {
+                const double d = 1.0 / 6.0;
+                auto Y = [&](int a, int b) { return y2[(N == 3) ? a * 3 + b : 0]; };
+                da = d * d * (Y(0, 0) + Y(0, 2) + Y(2, 0) + Y(2, 2) + 4.0 * (Y(0, 1) + Y(1, 0) + Y(1, 2) + Y(2, 1) + 4.0 * Y(1, 1)));
+            } else {
+                const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
+                da = d * d * ysum;
+            }
+            p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;                                      // OGG:185
+            if (MODE == QM_GUARD && guarded) p.fix_list[atomicAdd(p.fix_count, 1u)] = (unsigned)(out_r * p.nx + ci);
+        }
+    }
+}
+
+template <int N, int MODE>
+__global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams p, QuadRange rg) {
+    bipolar_quad_body<N, MODE>(p, rg, blockIdx.x, blockIdx.y);
+}
+
+// Literal re-evaluation (bp_point, OGG:41-95 operation for operation) of the cells the guard handed over: half a wave per
+// cell, one lane per Lobatto point (N*N <= 25 of 32 lanes), the lane of point 0 gathers the values with shuffles and sums
+// in the reference's order; overwrites the cell's dxq, dyq, daq (and dyq[.][nx] for the last cell of a row).  A cell is
+// re-evaluated iff one of ITS points is guarded, which depends on the cell alone: the result does not depend on tiling or
+// banding.
+template <int N>
+__global__ __launch_bounds__(64) void bipolar_quad_fixup_kernel(QuadParams p) {
+    constexpr int M = N - 1;
+    __shared__ double sdx[64], sdy[64];
+    const unsigned count = *p.fix_count;
+    const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+    const int jj = (q < N * N) ? q / N : 0, ii = (q < N * N) ? q % N : 0;
+    for (unsigned k0 = blockIdx.x * 2; k0 < count; k0 += gridDim.x * 2) {  // wave-uniform trip count
+        const unsigned k = k0 + half;
+        const bool have = k < count;
+        const unsigned lin = have ? p.fix_list[k] : 0u;
+        const long out_r = lin / p.nx, ci = lin % p.nx;
+        const long cj = p.j0 + out_r;
+        double dx = 0.0, dy = 0.0;
+        if (have && q < N * N) {
+            const BpRow r = p.row_tab[M * cj + jj];
+            const BpCol c = p.col_tab[M * ci + ii];
+            double phis, rden, h_i, h_j;
+            bp_point(r, c, p.rp, phis, h_i, h_j, rden);
+            dx = h_i * 2 * kPi / (double)p.nx;                        // OGG:131
+            dy = h_j * (90 - p.lat0_bp) * kPi180 / (double)p.ny;      // OGG:132
+        }
+        // Hand the values to the lane of point 0 through LDS (the barriers also keep the compiler from overlapping the
+        // gather with bp_point's register peak -- the kernel is latency-bound and wants occupancy).
+        __syncthreads();
+        sdx[lane] = dx;
+        sdy[lane] = dy;
+        __syncthreads();
+        if (!have || q != 0) continue;
+        const int base = half << 5;
+        double dxrow[N], dycol[N], dyright[N], y2[(N <= 3) ? N * N : 1];
+        double ysum = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                const double vx = sdx[base + a * N + b], vy = sdy[base + a * N + b];
+                if (a == 0) dxrow[b] = vx;
+                if (b == 0) dycol[a] = vy;
+                if (b == N - 1) dyright[a] = vy;
+                if (N <= 3)
+                    y2[(N <= 3) ? a * N + b : 0] = vx * vy;
+                else
+                    ysum = ysum + (quad_weight_1d<N>(b) * quad_weight_1d<N>(a)) * (vx * vy);   // OGG:244/252
+            }
+        }
+        p.dxq[out_r * p.nx + ci] = quad_average_1d<N>(dxrow) * p.Re;
+        p.dyq[out_r * (p.nx + 1) + ci] = quad_average_1d<N>(dycol) * p.Re;
+        if (ci == p.nx - 1) p.dyq[out_r * (p.nx + 1) + p.nx] = quad_average_1d<N>(dyright) * p.Re;
+        double da;
+        if (N == 2) {
+            const double d = 1.0 / 2.0;
+            da = d * d * (y2[0] + y2[1] + y2[(N <= 3) ? N : 0] + y2[(N <= 3) ? N + 1 : 0]);
+        } else if (N == 3) {
+            const double d = 1.0 / 6.0;
+            auto Y = [&](int a, int b) { return y2[(N == 3) ? a * 3 + b : 0]; };
+            da = d * d * (Y(0, 0) + Y(0, 2) + Y(2, 0) + Y(2, 2) + 4.0 * (Y(0, 1) + Y(1, 0) + Y(1, 2) + Y(2, 1) + 4.0 * Y(1, 1)));
+        } else {
+            const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
+            da = d * d * ysum;
+        }
+        p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;
+    }
+}
+
+// ---- bipolar_cap_ij_array (OGG:125-133) at arbitrary fractional indices ---------------------------------------
+__global__ void bipolar_ij_kernel(long n_i, const double* __restrict__ iv, long n_j, const double* __restrict__ jv, long Ni,
+                                  long Nj, double lat0_bp, double lon_bp, double rp, double* __restrict__ hi,
+                                  double* __restrict__ hj) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r = blockIdx.y;
+    if (k >= n_i || r >= n_j) return;
+    const double lon = lon_bp + (iv[k] * 360.0) / (double)Ni;
+    const double lat = lat0_bp + (jv[r] * (90 - lat0_bp)) / (double)Nj;
+    const BpRow row = bp_row(lat, rp);
+    const BpCol col = bp_col(lon, lon_bp);
+    double phis, h_i, h_j, rden;
+    bp_point(row, col, rp, phis, h_i, h_j, rden);
+    hi[r * n_i + k] = h_i * 2 * kPi / (double)Ni;
+    hj[r * n_i + k] = h_j * (90 - lat0_bp) * kPi180 / (double)Nj;
+}
+
+QuadNodes make_nodes(int order) {  // OGG:191-204, host IEEE double
+    QuadNodes q{};
+    if (order == 2) {
+        double a[] = {0.0, 1.0}, b[] = {1.0, 0.0};
+        for (int k = 0; k < 2; ++k) q.a[k] = a[k], q.b[k] = b[k];
+    } else if (order == 3) {
+        double a[] = {0.0, 0.5, 1.0}, b[] = {1.0, 0.5, 0.0};
+        for (int k = 0; k < 3; ++k) q.a[k] = a[k], q.b[k] = b[k];
+    } else if (order == 4) {
+        const double r5 = 0.5 / sqrt(5.0);
+        double a[] = {0.0, 0.5 - r5, 0.5 + r5, 1.0}, b[] = {1.0, 0.5 + r5, 0.5 - r5, 0.0};
+        for (int k = 0; k < 4; ++k) q.a[k] = a[k], q.b[k] = b[k];
+    } else if (order == 5) {
+        const double r37 = 0.5 * sqrt(3.0 / 7.0);
+        double a[] = {0.0, 0.5 - r37, 0.5, 0.5 + r37, 1.0}, b[] = {1.0, 0.5 + r37, 0.5, 0.5 - r37, 0.0};
+        for (int k = 0; k < 5; ++k) q.a[k] = a[k], q.b[k] = b[k];
+    }
+    return q;
+}
+
+template <int N>
+size_t quad_workspace_bytes(long nx, long ny, long n_cell_rows) {
+    constexpr int M = N - 1;
+    const size_t tabs = (size_t)(M * ny + 2) * sizeof(BpRow) + (size_t)(M * nx + 1) * sizeof(BpCol);
+    return tabs + 16 + (size_t)(n_cell_rows > 0 ? n_cell_rows : 0) * nx * sizeof(unsigned);
+}
+
+// Launch plan of one quadrature call: which cell rows run the plain algebraic form, which carry the guard, whether the
+// band owns the j = ny row; shared by the function-level entry point and by the fused pass (ogg_pass.hip).
+struct QuadPlan {
+    QuadParams p;
+    unsigned gx;                 // strip workgroups along the columns
+    bool has_fast, has_guard, has_top;
+    QuadRange fast, guard, top;
+};
+
+template <int N>
+int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, void* ws, long ws_bytes, QuadPlan& out) {
+    constexpr int M = N - 1;
+    const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
+    const size_t need = quad_workspace_bytes<N>(p.nx, p.ny, n_cell_rows);
+    OGG_REQUIRE(ws && (size_t)ws_bytes >= need, OGG_EARG, "bipolar quadrature workspace too small: %ld < %zu bytes", ws_bytes, need);
+    BpRow* row_tab = static_cast<BpRow*>(ws);
+    BpCol* col_tab = reinterpret_cast<BpCol*>(row_tab + n_rows);
+    unsigned* fix_count = reinterpret_cast<unsigned*>(col_tab + n_cols);
+    p.row_tab = row_tab;
+    p.col_tab = col_tab;
+    p.fix_count = fix_count;
+    p.fix_list = fix_count + 4;
+    p.guard_k = guard_k;
+    out.p = p;
+    const long n_strips = (p.nx + QS_CELLS - 1) / QS_CELLS;
+    out.gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);
+    // A point can only be guarded where cos^2(phis) < 1/K and phis never exceeds the grid latitude of its lattice row, so the
+    // cell rows whose top edge lies below acos(2/sqrt(K)) (a factor 4 of margin on cos^2) run without the guard.
+    long jg = 0;  // first cell row that carries the guard
+    if (guard_k > 4.0) {
+        const double lat_thr = acos(2.0 / sqrt(guard_k)) / kPi180;  // degrees
+        jg = (long)floor((double)p.ny * (lat_thr - p.lat0_bp) / (90.0 - p.lat0_bp)) - 1;
+    }
+    if (jg < 0) jg = 0;
+    if (jg > p.ny) jg = p.ny;
+    const long lo = p.j0, hi = p.j0 + n_cell_rows;
+    auto range = [&](long b, long e) {
+        QuadRange r{};
+        r.row_begin = b;
+        r.row_end = e;
+        // enough waves to fill 1024 SIMDs several times over, without recomputing more than a few % of the lattice rows
+        long target = 8192;
+        if (const char* ev = getenv("OGG_QUAD_TARGET_WAVES")) target = atol(ev) > 0 ? atol(ev) : target;
+        long rpc = ((e - b) * n_strips + target - 1) / target;
+        r.rows_per_chunk = rpc < 1 ? 1 : (rpc > 32 ? 32 : rpc);
+        r.gy = (unsigned)((e - b + r.rows_per_chunk - 1) / r.rows_per_chunk);
+        return r;
+    };
+    out.has_fast = lo < hi && lo < jg;
+    out.has_guard = lo < hi && hi > jg;
+    out.has_top = n_dx_rows > n_cell_rows;
+    if (out.has_fast) out.fast = range(lo, hi < jg ? hi : jg);
+    if (out.has_guard) out.guard = range(lo > jg ? lo : jg, hi);
+    out.top = QuadRange{};
+    out.top.top_row = 1;  // dxq[ny][:] from the exact j = ny lattice row: literal sequence
+    out.top.out_row = n_cell_rows;
+    out.top.gy = 1;
+    return OGG_OK;
+}
+
+constexpr unsigned FIXUP_BLOCKS = 2048;
+
+template <int N>
+int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
+    // workspace (row/column tables, fix-up counter and list): the caller's (graph-capturable: no allocation at all), or from
+    // the stream-ordered allocator (no host synchronisation, safe with concurrent streams)
+    const size_t need = quad_workspace_bytes<N>(p.nx, p.ny, n_cell_rows);
+    void* ws = ext_ws;
+    long ws_bytes = ext_ws_bytes;
+    if (!ext_ws) {
+        OGG_HIP_CHECK(hipMallocAsync(&ws, need, s));
+        ws_bytes = (long)need;
+    }
+    QuadPlan q;
+    if (int e = plan_quad<N>(p, n_dx_rows, n_cell_rows, guard_k, ws, ws_bytes, q)) return e;
+    bipolar_tables_kernel<N><<<tables_blocks<N>(q.p), 256, 0, s>>>(q.p);
+    OGG_LAUNCH_CHECK();
+    if (q.has_fast) {
+        bipolar_quad_kernel<N, QM_FAST><<<dim3(q.gx, q.fast.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.fast);
+        OGG_LAUNCH_CHECK();
+    }
+    if (q.has_guard) {
+        bipolar_quad_kernel<N, QM_GUARD><<<dim3(q.gx, q.guard.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.guard);
+        OGG_LAUNCH_CHECK();
+        bipolar_quad_fixup_kernel<N><<<FIXUP_BLOCKS, 64, 0, s>>>(q.p);
+        OGG_LAUNCH_CHECK();
+    }
+    if (q.has_top) {
+        bipolar_quad_kernel<N, QM_LITERAL><<<dim3(q.gx, 1), 64 * QS_WAVES, 0, s>>>(q.p, q.top);
+        OGG_LAUNCH_CHECK();
+    }
+    if (!ext_ws) OGG_HIP_CHECK(hipFreeAsync(ws, s));
+    return OGG_OK;
+}
+
+}  // namespace

@@ -1,161 +1,13 @@
-// K1+K2 fused for sub-grids that are lat-lon BY CONSTRUCTION (Mercator, Southern Ocean, regular southern cap):
-// x[j][i] = lon[i], y[j][i] = lat[j] (OGG:430-432, 840-841), so every term of the MIDAS metrics (OGG:695-713) and of
-// angle_x (OGG:725-728) factors into a per-row scalar times a per-column scalar.  The kernel evaluates the 1-D axes
-// itself (OGG:336, 431, 834-835: one atan(sinh) or one multiply-divide-add per row / column), the transcendental functions
-// once per ROW in LDS, and streams out all six fields of up to four sub-grid bands in ONE launch: 48 B written per cell,
-// nothing read from HBM -- the algorithmic minimum of SURVEY 8(d).
-//
-// It is bit-identical to tile_latlon_kernel followed by midas_angle_kernel, because it performs the same operations on
-// the same operands and only hoists those that do not depend on i (or on j):
-//   dy_i = (lat_j - lat_j) PI/180 = 0, so dx = Re sqrt(0 + (dlam_i cos(lv_j))^2);  lv_j = (0.5 (lat_j+lat_j)) PI/180 = lat_j PI/180
-//   dx_j = mdist(lon_i, lon_i) PI/180 = 0, so dy = Re sqrt(dphi_j^2 + 0) is a per-row constant
-//   area = Re^2 ((0.5 (dlam_i + dlam_i)) (sin lv_{j+1} - sin lv_j))
-//   angle = atan2(+0, (lon_{i+1} - lon_{i-1}) cos(lat_j PI/180)) / (PI/180): the IEEE value of atan2(+0, p) is +0 for
-//           p > 0 or p = +0 and pi for p < 0 or p = -0.
-// tests/test_gpu_pipeline.py checks the bit-identity against the generic stencil kernel.
-#include <cstdlib>
-
-#include "ogg_common.h"
-#include "ogg_math.h"
-
-namespace {
-using namespace ogg;
-
-constexpr int LF_TX = 256;
-constexpr int LF_ROWS = 32;  // maximum rows per workgroup (LDS row table); small bands use fewer so that the grid stays >= ~2000 workgroups
-constexpr int LF_MAX_BANDS = 4;
-
-struct FusedParams {
-    int n_bands;
-    ogg_latlon_band band[LF_MAX_BANDS];
-    long strip0[LF_MAX_BANDS + 1];  // prefix sum of the row strips of the bands
-    long ni1;
-    double lon0, lenlon, Ni;        // lon[i] = lon0 + (i*lenlon)/Ni   (OGG:431, 834)
-    int rows_per_block;
-    double Re, Re2;
-    int metrics;
-};
-
-struct RowScalars {
-    double lat, sl, cl, dy;
-};
-
-// latitude of axis index k (OGG:336 / OGG:835 / explicit)
-OGG_DEV double axis_lat(const ogg_latlon_band& b, long k, double Ni) {
-    if (b.axis_kind == 0) return b.a0 + ((double)k * b.len) / b.denom;
-    if (b.axis_kind == 1) {
-        const double R = Ni / (2 * kPi);
-        return atan(sinh((double)(b.y0 + k) / R)) * k180Pi;
-    }
-    return b.lat1d[k];
-}
-
-__global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
-    __shared__ RowScalars s_row[LF_ROWS + 1];
-    const int tid = threadIdx.x;
-    const long i = (long)blockIdx.x * LF_TX + tid;
-    const long ni1 = p.ni1, ni = ni1 - 1;
-    // column-only quantities (OGG:696, 713, 725-727)
-    const long ic = (i < ni1) ? i : ni;
-    const double lon_c = p.lon0 + ((double)ic * p.lenlon) / p.Ni;
-    const double lon_r = p.lon0 + ((double)((ic + 1 < ni1) ? ic + 1 : ic) * p.lenlon) / p.Ni;
-    const double lon_l = p.lon0 + ((double)((ic > 0) ? ic - 1 : 0) * p.lenlon) / p.Ni;
-    const double dlam = mdist(lon_r, lon_c) * kPi180;
-    const double hdlam = 0.5 * (dlam + dlam);
-    double xdiff;
-    if (i == 0)
-        xdiff = lon_r - lon_c;
-    else if (i == ni)
-        xdiff = lon_c - lon_l;
-    else
-        xdiff = lon_r - lon_l;
-    const bool has_r = i < ni;
-    const double pi_deg = kPi / kPi180;
-    // Row strips of all bands are taken grid-stride: the launch caps the number of resident workgroups (an HBM-write-bound
-    // kernel needs only a few waves per SIMD) so that a VALU-bound kernel running on another stream can share the CUs.
-    const long total = p.strip0[p.n_bands];
-    for (long strip = blockIdx.y; strip < total; strip += gridDim.y) {
-        int bi = 0;
-        while (bi + 1 < p.n_bands && strip >= p.strip0[bi + 1]) ++bi;
-        const ogg_latlon_band& b = p.band[bi];
-        const long n_cell_rows = p.metrics ? b.n_cell_rows : 0;
-        const long js = (strip - p.strip0[bi]) * p.rows_per_block;
-        const long je = (js + p.rows_per_block < b.n_pt_rows) ? js + p.rows_per_block : b.n_pt_rows;
-        const int nrows = (int)(je - js);
-        // per-row scalars for rows js .. je (row je only when a cell row needs it)
-        if (tid <= nrows) {
-            const long j = js + tid;
-            const bool have = (tid < nrows) || (j - 1 < n_cell_rows);
-            RowScalars r = {0.0, 0.0, 0.0, 0.0};
-            if (have) {
-                r.lat = axis_lat(b, b.k0 + j, p.Ni);
-                const double lv = (0.5 * (r.lat + r.lat)) * kPi180;
-                sincos(lv, &r.sl, &r.cl);
-            }
-            s_row[tid] = r;
-        }
-        __syncthreads();
-        if (p.metrics && tid < nrows) {  // dy of cell row j needs lat_{j+1}
-            const long j = js + tid;
-            if (j < n_cell_rows) {
-                const double dyj = (s_row[tid + 1].lat - s_row[tid].lat) * kPi180;
-                s_row[tid].dy = p.Re * sqrt(dyj * dyj + 0.0);
-            }
-        }
-        __syncthreads();
-        if (i < ni1) {
-            for (int r = 0; r < nrows; ++r) {
-                const long j = js + r;
-                const RowScalars rs = s_row[r];
-                b.x[j * ni1 + i] = lon_c;
-                b.y[j * ni1 + i] = rs.lat;
-                const double pa = xdiff * rs.cl;
-                const bool zero = (pa > 0.0) || (pa == 0.0 && !signbit(pa));
-                b.angle[j * ni1 + i] = (pa != pa) ? pa : (zero ? 0.0 / kPi180 : pi_deg);
-                if (p.metrics) {
-                    if (has_r) {
-                        const double t = dlam * rs.cl;
-                        b.dx[j * ni + i] = p.Re * sqrt(0.0 + t * t);
-                    }
-                    if (j < n_cell_rows) {
-                        b.dy[j * ni1 + i] = rs.dy;
-                        if (has_r) b.area[j * ni + i] = p.Re2 * (hdlam * (s_row[r + 1].sl - rs.sl));
-                    }
-                }
-            }
-        }
-        __syncthreads();  // the row table is rewritten by the next strip
-    }
-}
-
-}  // namespace
+// Lat-lon sub-grids, all six fields in one launch -- C-ABI entry points; the kernel is in ogg_latlon_fused_dev.h.
+#include "ogg_latlon_fused_dev.h"
 
 extern "C" int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band* bands, long ni1, double lon0, double lenlon,
                                               double Re, int metrics, void* stream) {
-    OGG_REQUIRE(n_bands >= 0 && n_bands <= LF_MAX_BANDS && (n_bands == 0 || bands) && ni1 >= 2, OGG_EARG,
-                "ogg_latlon_supergrid_multi: bad argument (at most %d bands)", LF_MAX_BANDS);
-    FusedParams p{};
-    long total_rows = 0, points = 0;
-    for (int k = 0; k < n_bands; ++k) {
-        const ogg_latlon_band& b = bands[k];
-        OGG_REQUIRE(b.n_pt_rows >= 0 && b.n_cell_rows >= 0 && b.n_cell_rows <= b.n_pt_rows, OGG_ESHAPE,
-                    "ogg_latlon_supergrid_multi: band %d rows pt=%ld cell=%ld", k, b.n_pt_rows, b.n_cell_rows);
-        if (b.n_pt_rows == 0) continue;
-        OGG_REQUIRE(b.x && b.y && b.angle && (b.axis_kind != 2 || b.lat1d), OGG_EARG, "ogg_latlon_supergrid_multi: null pointer in band %d", k);
-        OGG_REQUIRE(!metrics || (b.dx && (b.n_cell_rows == 0 || (b.dy && b.area))), OGG_EARG,
-                    "ogg_latlon_supergrid_multi: null metrics output in band %d", k);
-        p.band[p.n_bands++] = b;
-        total_rows += b.n_pt_rows;
-        points += b.n_pt_rows * ni1;
-    }
+    FusedParams p;
+    long points = 0;
+    if (int e = plan_latlon(n_bands, bands, ni1, lon0, lenlon, Re, metrics, p, points)) return e;
     if (p.n_bands == 0) return OGG_OK;
     const long gx = (ni1 + LF_TX - 1) / LF_TX;
-    long rpb = (total_rows * gx + 2047) / 2048;  // aim at >= 2048 row strips x column tiles
-    rpb = rpb < 4 ? 4 : (rpb > LF_ROWS ? LF_ROWS : rpb);
-    p.strip0[0] = 0;
-    for (int k = 0; k < p.n_bands; ++k) p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
-    p.ni1 = ni1, p.lon0 = lon0, p.lenlon = lenlon, p.Ni = (double)(ni1 - 1);
-    p.rows_per_block = (int)rpb, p.Re = Re, p.Re2 = pow(Re, 2.0), p.metrics = metrics;
     // Resident workgroups: ~115 (measured: 92 already slow the kernel by 20 %, 69 by 60 %) saturate the HBM write path on a large launch (measured), which leaves the CUs to a
     // concurrent VALU-bound kernel; small launches are latency-bound and take the whole chip.
     long max_wg = points >= 8000000 ? 115 : (points >= 2000000 ? 512 : 2048);

@@ -1,0 +1,206 @@
+// One rank's whole pass over a tripolar supergrid (the sub-grid loop of OGG:1100-1313) in THREE launches on one stream.
+//
+// The lat-lon sub-grids are HBM-write bound (48 B/cell, a few waves per CU saturate the write path), the bipolar cap is
+// fp64-VALU bound (mesh: asin/atan/atan2 per point; quadrature: (N-1)^2 lattice points per cell).  Instead of putting them
+// on separate streams -- which costs 10-20 us of cross-queue signalling per dependency, as much as the kernels themselves
+// once the grid is split over 8 GPUs -- each launch carries workgroups of BOTH kinds, told apart by their workgroup index:
+//
+//   launch A:  lat-lon row strips [0, s1)  |  j = ny row of the quadrature (literal)  |  row/column tables  |  cap mesh + angle
+//   launch B:  lat-lon row strips [s1, S)  |  quadrature strips with the guard  |  quadrature strips without
+//   launch C:  literal fix-up of the cells the guard handed over
+//
+// The lat-lon workgroups come first in the index space (they are resident from the start and walk their strips grid-stride
+// while the compute workgroups stream through the remaining slots); s1 splits the lat-lon strips in proportion to the
+// estimated VALU time of launches A and B.  Every workgroup runs the same body function as the stand-alone kernels of
+// ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level entry points.
+#include "ogg_bipolar_dev.h"
+#include "ogg_latlon_fused_dev.h"
+
+namespace {
+
+constexpr int PASS_TX = 256;
+static_assert(PASS_TX == LF_TX && PASS_TX == 64 * MESH_WAVES && PASS_TX == 64 * QS_WAVES, "one workgroup shape for all roles");
+
+struct LatlonShare {
+    long n_wg;      // workgroups of this launch that stream lat-lon strips (gx * gy)
+    long gx, gy;
+    long strip_lo, strip_hi;
+};
+
+union PassLds {
+    RowScalars ll[LF_ROWS + 1];
+    BpRow mesh[MESH_ROWS];
+};
+
+struct PassAParams {
+    FusedParams ll;
+    LatlonShare share;
+    MeshParams mesh;
+    long mesh_gx, n_mesh;   // mesh workgroups: mesh_gx column tiles x row tiles
+    QuadParams q;
+    QuadRange top;
+    long n_top, n_tab;      // workgroups of the j = ny row and of the tables
+};
+
+template <int N>
+__global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
+    __shared__ PassLds lds;
+    long b = blockIdx.x;
+    if (b < a.share.n_wg) {
+        latlon_fused_body(a.ll, lds.ll, b % a.share.gx, b / a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        return;
+    }
+    b -= a.share.n_wg;
+    if (b < a.n_top) {
+        bipolar_quad_body<N, QM_LITERAL>(a.q, a.top, b, 0);
+        return;
+    }
+    b -= a.n_top;
+    if (b < a.n_tab) {
+        bipolar_tables_body<N>(a.q, b);
+        return;
+    }
+    b -= a.n_tab;
+    if (b < a.n_mesh) bipolar_mesh_body(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
+}
+
+struct PassBParams {
+    FusedParams ll;
+    LatlonShare share;
+    QuadParams q;
+    QuadRange guard, fast;
+    long gx, n_guard, n_fast;
+};
+
+template <int N>
+__global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
+    __shared__ RowScalars lds[LF_ROWS + 1];
+    long b = blockIdx.x;
+    if (b < a.share.n_wg) {
+        latlon_fused_body(a.ll, lds, b % a.share.gx, b / a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        return;
+    }
+    b -= a.share.n_wg;
+    if (b < a.n_guard) {
+        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, b % a.gx, b / a.gx);
+        return;
+    }
+    b -= a.n_guard;
+    if (b < a.n_fast) bipolar_quad_body<N, QM_FAST>(a.q, a.fast, b % a.gx, b / a.gx);
+}
+
+long env_long(const char* name, long dflt) {
+    const char* e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
+LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone) {
+    LatlonShare s{};
+    s.gx = (ni1 + LF_TX - 1) / LF_TX;
+    s.strip_lo = lo, s.strip_hi = hi;
+    if (hi <= lo) return s;
+    // resident lat-lon workgroups: enough to keep the HBM write path busy and not more, so that the VALU-bound workgroups of
+    // the same launch get the remaining wave slots; a launch without compute workgroups takes the whole chip
+    const long points = (hi - lo) * ll.rows_per_block * ni1;
+    long max_wg = alone ? 2048 : (points >= 4000000 ? env_long("OGG_PASS_LL_WG", 115) : env_long("OGG_PASS_LL_WG_SMALL", 184));
+    long gy = hi - lo;
+    if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
+    s.gy = gy < 1 ? 1 : gy;
+    s.n_wg = s.gx * s.gy;
+    return s;
+}
+
+template <int N>
+int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, hipStream_t st) {
+    const long n_strips_ll = ll.n_bands ? ll.strip0[ll.n_bands] : 0;
+    const bool have_cap = cap && cap->n_pt_rows > 0;
+    const bool have_quad = have_cap && metrics;
+    PassAParams A{};
+    PassBParams B{};
+    QuadPlan qp{};
+    A.ll = ll, B.ll = ll;
+    if (have_cap) {
+        A.mesh = MeshParams{cap->Ni, cap->Nj, cap->lat0_bp, cap->lon_bp, cap->j0, cap->n_pt_rows, cap->x, cap->y, nullptr, nullptr, cap->angle, MESH_ROWS};
+        const dim3 mg = mesh_grid(A.mesh);
+        A.mesh_gx = mg.x, A.n_mesh = (long)mg.x * mg.y;
+    }
+    if (have_quad) {
+        double guard_k = 1000.0;
+        if (const char* e = getenv("OGG_BP_GUARD_K")) guard_k = atof(e);
+        QuadParams p{};
+        p.nx = cap->Ni, p.ny = cap->Nj, p.lat0_bp = cap->lat0_bp, p.lon_bp = cap->lon_bp, p.rp = cap->rp, p.Re = cap->Re, p.j0 = cap->j0;
+        p.dxq = cap->dx, p.dyq = cap->dy, p.daq = cap->area, p.q = make_nodes(N);
+        if (int e = plan_quad<N>(p, cap->n_pt_rows, cap->n_cell_rows, guard_k, cap->workspace, cap->workspace_bytes, qp)) return e;
+        A.q = qp.p, B.q = qp.p;
+        A.top = qp.top;
+        A.top.top_row = 2;  // the tables are written by this same launch
+        A.n_top = qp.has_top ? qp.gx : 0, A.n_tab = tables_blocks<N>(qp.p);
+        B.gx = qp.gx;
+        B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.gx * qp.guard.gy : 0;
+        B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.gx * qp.fast.gy : 0;
+    }
+    // split of the lat-lon strips between the two launches: in proportion to their VALU time (per cap row, measured at
+    // 1/8 degree: mesh 1, plain quadrature 2.1, guarded quadrature 3.1)
+    long s1 = n_strips_ll;
+    const bool launch_b = have_quad && (B.n_guard + B.n_fast > 0);
+    if (launch_b) {
+        const double ta = have_cap ? (double)cap->n_pt_rows : 0.0;
+        const double tb = (qp.has_fast ? 2.1 * (double)(qp.fast.row_end - qp.fast.row_begin) : 0.0) +
+                          (qp.has_guard ? 3.1 * (double)(qp.guard.row_end - qp.guard.row_begin) : 0.0);
+        double f = ta / (ta + tb);
+        if (const char* e = getenv("OGG_PASS_SPLIT")) f = atof(e);
+        s1 = (long)llround(f * (double)n_strips_ll);
+        s1 = s1 < 0 ? 0 : (s1 > n_strips_ll ? n_strips_ll : s1);
+    }
+    A.share = make_share(ll, 0, s1, ni1, !have_cap);
+    const long na = A.share.n_wg + A.n_top + A.n_tab + A.n_mesh;
+    if (na > 0) {
+        pass_a_kernel<N><<<(unsigned)na, PASS_TX, 0, st>>>(A);
+        OGG_LAUNCH_CHECK();
+    }
+    if (launch_b) {
+        B.share = make_share(ll, s1, n_strips_ll, ni1, false);
+        const unsigned nb = (unsigned)(B.share.n_wg + B.n_guard + B.n_fast);
+        pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
+        OGG_LAUNCH_CHECK();
+        if (qp.has_guard) {
+            bipolar_quad_fixup_kernel<N><<<FIXUP_BLOCKS, 64, 0, st>>>(qp.p);
+            OGG_LAUNCH_CHECK();
+        }
+    }
+    return OGG_OK;
+}
+
+}  // namespace
+
+extern "C" int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
+                                     int metrics, const ogg_bipolar_band* cap, void* stream) {
+    FusedParams ll;
+    long points = 0;
+    if (int e = plan_latlon(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, ll, points)) return e;
+    int order = 5;
+    if (cap && cap->n_pt_rows > 0) {
+        OGG_REQUIRE(cap->Ni + 1 == ni1, OGG_ESHAPE, "ogg_tripolar_pass: cap has %ld columns, the lat-lon bands %ld", cap->Ni + 1, ni1);
+        OGG_REQUIRE(cap->Nj > 0 && cap->j0 >= 0 && cap->j0 + cap->n_pt_rows <= cap->Nj + 1, OGG_ESHAPE,
+                    "ogg_tripolar_pass: cap rows %ld..%ld outside 0..%ld", cap->j0, cap->j0 + cap->n_pt_rows, cap->Nj);
+        OGG_REQUIRE(cap->x && cap->y && cap->angle, OGG_EARG, "ogg_tripolar_pass: null cap output");
+        if (metrics) {
+            order = cap->order;
+            OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
+            OGG_REQUIRE(cap->dx && (cap->n_cell_rows <= 0 || (cap->dy && cap->area)), OGG_EARG, "ogg_tripolar_pass: null cap metrics output");
+            OGG_REQUIRE(cap->n_cell_rows >= 0 && cap->j0 + cap->n_cell_rows <= cap->Nj &&
+                            (cap->n_pt_rows == cap->n_cell_rows ||
+                             (cap->n_pt_rows == cap->n_cell_rows + 1 && cap->j0 + cap->n_cell_rows == cap->Nj)),
+                        OGG_ESHAPE, "ogg_tripolar_pass: cap band j0=%ld cell rows=%ld point rows=%ld of Nj=%ld", cap->j0,
+                        cap->n_cell_rows, cap->n_pt_rows, cap->Nj);
+            OGG_REQUIRE(cap->workspace, OGG_EARG, "ogg_tripolar_pass: the cap needs a workspace (ogg_bipolar_quad_workspace_bytes)");
+        }
+    }
+    hipStream_t st = ogg::as_stream(stream);
+    switch (order) {
+        case 2: return launch_pass<2>(ll, ni1, metrics, cap, st);
+        case 3: return launch_pass<3>(ll, ni1, metrics, cap, st);
+        case 4: return launch_pass<4>(ll, ni1, metrics, cap, st);
+        default: return launch_pass<5>(ll, ni1, metrics, cap, st);
+    }
+}

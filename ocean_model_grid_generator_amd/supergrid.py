@@ -18,6 +18,7 @@ sub-grids on the host exactly as the reference does (OGG:1315-1365).
 
 torch is used for device memory, streams, graphs and torch.distributed only; every number is produced by libogg_hip.so.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -182,6 +183,9 @@ class Supergrid(object):
         self.device = torch.device(device)
         self.peers = peers  # halo="local": list of all virtual ranks' Supergrid objects
         self.overlap = True
+        # "pass": lat-lon sub-grids + bipolar cap through ogg_tripolar_pass_dev (three launches on one stream, the two kinds
+        # of work sharing each launch); "kernels": one call per sub-grid and phase, on side streams when `overlap` is set
+        self.launch = "kernels"
         self._side = None
         self.buf = {}
         self.timings = {}
@@ -248,6 +252,46 @@ class Supergrid(object):
     def _selected(s, only, kinds):
         return (only is None or s.name == only) and (kinds is None or s.kind in kinds)
 
+    def _latlon_bands(self, only=None, kinds=None):
+        """ogg_latlon_band descriptors of this rank's lat-lon sub-grid bands."""
+        bands = []
+        for s in self.plan.subs:
+            b = self.buf[s.name]
+            if b["n"] == 0 or not self._selected(s, only, kinds) or s.kind not in ("mercator", "latlon"):
+                continue
+            band = L.LatlonBand()
+            if s.kind == "mercator":
+                band.axis_kind, band.y0 = 1, s.y0
+            else:
+                band.axis_kind, band.a0, band.len, band.denom = 0, s.lat0, s.lenlat, float(s.lnj)
+            band.k0, band.n_pt_rows, band.n_cell_rows = s.row0 + b["lo"], b["n"], b["n_cell"]
+            band.x, band.y, band.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
+            band.dx = b["dx"].data_ptr()
+            band.dy = b["dy"].data_ptr() if b["n_cell"] else None
+            band.area = b["area"].data_ptr() if b["n_cell"] else None
+            bands.append(band)
+        return bands
+
+    def tripolar_pass(self):
+        """Lat-lon sub-grids and the bipolar cap of this rank through ogg_tripolar_pass_dev."""
+        p, st = self.plan, self._stream()
+        bands = self._latlon_bands()
+        arr = (L.LatlonBand * max(len(bands), 1))(*bands)
+        cap = None
+        for s in p.subs:
+            b = self.buf[s.name]
+            if s.kind == "bipolar" and b["n"] > 0:
+                cap = L.BipolarBand()
+                cap.Ni, cap.Nj, cap.lat0_bp, cap.lon_bp, cap.rp, cap.Re, cap.order = p.Ni, s.Nj, s.lat0_bp, s.lon_bp, s.rp, p.Re, 5
+                cap.j0, cap.n_pt_rows, cap.n_cell_rows = b["lo"], b["n"], b["n_cell"]
+                cap.x, cap.y, cap.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
+                cap.dx = b["dx"].data_ptr()
+                cap.dy = b["dy"].data_ptr() if b["n_cell"] else None
+                cap.area = b["area"].data_ptr() if b["n_cell"] else None
+                cap.workspace, cap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
+        self._timed("tripolar_pass", lambda: L.call("ogg_tripolar_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re,
+                                                    0 if p.skip_metrics else 1, ctypes.byref(cap) if cap is not None else None, st))
+
     def phase_a(self, only=None, kinds=None):
         """Coordinates of this rank's bands (optionally of one sub-grid / of some kinds of sub-grid only)."""
         p, st = self.plan, self._stream()
@@ -255,22 +299,7 @@ class Supergrid(object):
         if only is None and self.latlon != "fused":
             L.call("ogg_linear_axis_dev", ni1, p.lon0, p.lenlon, float(p.Ni), self.lon1d.data_ptr(), st)
         if self.latlon == "fused":
-            bands = []
-            for s in p.subs:
-                b = self.buf[s.name]
-                if b["n"] == 0 or not self._selected(s, only, kinds) or s.kind not in ("mercator", "latlon"):
-                    continue
-                band = L.LatlonBand()
-                if s.kind == "mercator":
-                    band.axis_kind, band.y0 = 1, s.y0
-                else:
-                    band.axis_kind, band.a0, band.len, band.denom = 0, s.lat0, s.lenlat, float(s.lnj)
-                band.k0, band.n_pt_rows, band.n_cell_rows = s.row0 + b["lo"], b["n"], b["n_cell"]
-                band.x, band.y, band.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
-                band.dx = b["dx"].data_ptr()
-                band.dy = b["dy"].data_ptr() if b["n_cell"] else None
-                band.area = b["area"].data_ptr() if b["n_cell"] else None
-                bands.append(band)
+            bands = self._latlon_bands(only, kinds)
             if bands:
                 arr = (L.LatlonBand * len(bands))(*bands)
                 self._timed("latlon_fused", lambda: L.call("ogg_latlon_supergrid_multi_dev", len(bands), arr, ni1, p.lon0, p.lenlon, p.Re,
@@ -380,6 +409,13 @@ class Supergrid(object):
         lat-lon sub-grids (the HBM-bound lat-lon kernel overlaps the VALU-bound quadratures); everything joins back on
         the caller's stream before returning.  Under graph capture this becomes a forked graph."""
         torch = self.torch
+        if self.latlon == "fused" and self.launch == "pass":
+            self.tripolar_pass()
+            if self.plan.skip_metrics:
+                self.phase_b(kinds=("mercator", "latlon", "bipolar"))  # the -1 fill of OGG:1327-1329
+            self.phase_a(kinds=("dpole",))
+            self.phase_b(kinds=("dpole",))
+            return
         if self.latlon != "fused" or self.device.type != "cuda" or not self.overlap:
             self.phase_a()
             self.exchange_halo()
@@ -389,9 +425,10 @@ class Supergrid(object):
         caps = [s for s in self.plan.subs if s.kind in ("bipolar", "dpole")]
         # independent pieces of work: mesh (+ angle) and quadrature of every cap, one stream each
         tasks = []
+        for s in caps:  # the quadratures are the longest chains: enqueue them first
+            tasks.append(lambda s=s: self.phase_b(only=s.name))
         for s in caps:
             tasks.append(lambda s=s: self.phase_a(only=s.name))
-            tasks.append(lambda s=s: self.phase_b(only=s.name))
         if self._side is None or len(self._side) < len(tasks):
             self._side = [torch.cuda.Stream(self.device) for _ in tasks]
         fork = torch.cuda.Event()

@@ -1,0 +1,55 @@
+"""Sweep the tuning knobs of ogg_tripolar_pass_dev (read from the environment at every call) on one GPU.
+
+usage: python scripts/pass_sweep.py [--as-rank R --as-world W] [--workload r8]
+"""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ocean_model_grid_generator_amd import supergrid  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--as-rank", type=int, default=0)
+ap.add_argument("--as-world", type=int, default=1)
+ap.add_argument("--workload", default="r8")
+ap.add_argument("--wg", default="115,160,230,320,460")
+ap.add_argument("--wg-small", default="")
+ap.add_argument("--split", default="0.2,0.3,0.4")
+ap.add_argument("--steps", type=int, default=50)
+args = ap.parse_args()
+plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
+sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device="cuda:0", halo="recompute")
+sg.launch = "pass"
+
+
+def timeit():
+    for _ in range(3):
+        sg.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sg.run_pass()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / args.steps * 1e3
+
+
+print("default: %.4f ms" % timeit())
+for mr, tw in itertools.product((1, 2, 4, 8), (2048, 4096, 8192, 16384)):
+    os.environ["OGG_MESH_ROWS"], os.environ["OGG_QUAD_TARGET_WAVES"] = str(mr), str(tw)
+    print("mesh rows/wg=%d quad target waves=%d: %.4f ms" % (mr, tw, timeit()), flush=True)
+os.environ.pop("OGG_MESH_ROWS"), os.environ.pop("OGG_QUAD_TARGET_WAVES")
+key = "OGG_PASS_LL_WG_SMALL" if args.wg_small else "OGG_PASS_LL_WG"
+wgs = (args.wg_small or args.wg).split(",")
+for wg, sp in itertools.product(wgs, args.split.split(",")):
+    os.environ[key] = wg
+    if sp == "auto":
+        os.environ.pop("OGG_PASS_SPLIT", None)
+    else:
+        os.environ["OGG_PASS_SPLIT"] = sp
+    print("%s=%s split=%s: %.4f ms" % (key, wg, sp, timeit()), flush=True)

@@ -78,6 +78,32 @@ def test_fused_latlon_kernel_is_bit_identical_to_stencil(sg, name, world):
         assert np.array_equal(stencil[f], fused[f]), (f, world)
 
 
+def run_pass_mode(sg, plan, world=1):
+    import torch
+    out = []
+    for r in range(world):
+        g = sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo="recompute", latlon="fused")
+        for f in FIELDS:  # poison: every element must be written by the pass
+            for s in plan.subs:
+                g.buf[s.name][f].fill_(float("nan"))
+        g.launch = "pass"
+        g.step()
+        torch.cuda.synchronize()
+        out.append(g.bands_to_host())
+    return sg.stitch(plan, out)
+
+
+@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r2_skip_metrics", "r0.5_dp", "r0.5_latdp", "r0.25_even"])
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_tripolar_pass_is_bit_identical_to_separate_kernels(sg, name, world):
+    """ogg_tripolar_pass_dev (lat-lon strips and cap workgroups sharing three launches) against one launch per sub-grid and phase."""
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    kernels = run(sg, plan, 1, latlon="fused")
+    fused = run_pass_mode(sg, plan, world)
+    for f in FIELDS:
+        assert np.array_equal(kernels[f], fused[f], equal_nan=False), (f, world)
+
+
 def test_more_ranks_than_rows(sg):
     """Tiny sub-grids: some ranks own no rows of a sub-grid, the top band may own only the fold row."""
     plan = sg.SupergridPlan(0.25, ensure_nj_even=True)
