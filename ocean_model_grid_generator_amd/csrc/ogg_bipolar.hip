@@ -26,7 +26,10 @@ int ogg_bipolar_cap_mesh_angle_dev(long Ni, long Nj, double lat0_bp, double lon_
     if (nrows == 0) return OGG_OK;
     MeshParams m{Ni, Nj, lat0_bp, lon_bp, j0, nrows, lams, phis, h_i_inv, h_j_inv, angle_dx, MESH_ROWS};
     const dim3 grid = mesh_grid(m);
-    bipolar_mesh_kernel<<<grid, 64 * MESH_WAVES, 0, ogg::as_stream(stream)>>>(m);
+    if (h_i_inv || h_j_inv)
+        bipolar_mesh_kernel<true><<<grid, 64 * MESH_WAVES, 0, ogg::as_stream(stream)>>>(m);
+    else
+        bipolar_mesh_kernel<false><<<grid, 64 * MESH_WAVES, 0, ogg::as_stream(stream)>>>(m);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }

@@ -173,7 +173,9 @@ struct MeshParams {
     int rows_per_wg;   // 1..MESH_ROWS
 };
 
-// workgroup (bx, by) of the mesh grid; s_row: MESH_ROWS entries of LDS
+// workgroup (bx, by) of the mesh grid; s_row: MESH_ROWS entries of LDS.  WITH_H = false leaves the scale factors out of the
+// code (the pass never asks for them; with them the kernel needs 183 VGPRs = 2 waves per SIMD).
+template <bool WITH_H>
 OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long by) {
     const long Ni = m.Ni, Nj = m.Nj, j0 = m.j0, nrows = m.nrows;
     const double lat0_bp = m.lat0_bp, lon_bp = m.lon_bp;
@@ -212,7 +214,7 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
             lams[jl * ni1 + i] = lam;
             phis[jl * ni1 + i] = phi;
         }
-        if (hi || hj) {
+        if (WITH_H && (hi || hj)) {
             double ps, h_i, h_j, rd;
             bp_point(row, c, rp, ps, h_i, h_j, rd);
             if (out && hi && i < Ni) hi[jl * Ni + i] = h_i * 2 * kPi / (double)Ni;                    // OGG:119
@@ -234,9 +236,10 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
     }
 }
 
+template <bool WITH_H>
 __global__ __launch_bounds__(64 * MESH_WAVES) void bipolar_mesh_kernel(MeshParams m) {
     __shared__ BpRow s_row[MESH_ROWS];
-    bipolar_mesh_body(m, s_row, blockIdx.x, blockIdx.y);
+    bipolar_mesh_body<WITH_H>(m, s_row, blockIdx.x, blockIdx.y);
 }
 
 // sets m.rows_per_wg.  The column-only factors (sincos + two fmod) cost about as much as half a point, so a wave keeps
@@ -270,8 +273,7 @@ struct QuadRange {     // the part of the band one grid of strip workgroups eval
     long row_begin;    // cell rows [row_begin, row_end)
     long row_end;
     long rows_per_chunk;  // cell rows one wave walks (its first lattice row is recomputed: 1/((N-1)*rows_per_chunk) extra)
-    int top_row;       // 1: evaluate only dxq[ny][:] (exact j = ny lattice row) into band row out_row; 2: same, computing the
-                       //    row / column factors instead of reading the tables
+    int top_row;       // 1: evaluate only dxq[ny][:] (exact j = ny lattice row) into band row out_row
     long out_row;
     unsigned gy;       // workgroups along the rows
 };
@@ -396,11 +398,10 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
 }
 
 template <int N, int MODE>
-OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long bx, long by) {
+OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long strip, long by) {  // strip: per wave
     constexpr int M = N - 1;
     constexpr bool FAITHFUL = (MODE == QM_LITERAL);
     const int lane = threadIdx.x & 63;
-    const long strip = bx * QS_WAVES + (threadIdx.x >> 6);
     if (strip * QS_CELLS >= p.nx) return;  // wave-uniform
     const long ci = strip * QS_CELLS + lane;
     const long n_cols_tab = M * p.nx + 1;
@@ -409,24 +410,14 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long bx
     for (int ii = 0; ii < M; ++ii) {
         long u = M * ci + ii;
         if (u > n_cols_tab - 1) u = n_cols_tab - 1;
-        if (rg.top_row == 2) {  // tables not available yet (same launch): the expressions of bipolar_tables_body
-            const double iv = lattice_node(p.q, (int)(u % M), u / M);
-            col[ii] = bp_col(p.lon_bp + (iv * 360.0) / (double)p.nx, p.lon_bp);
-        } else {
-            col[ii] = p.col_tab[u];
-        }
+        col[ii] = p.col_tab[u];
     }
     const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
     const double sx = (2 * kPi) / (double)p.nx, sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
     const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
     RowEval<N, MODE> cur;
     if (rg.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
-        BpRow rt;
-        if (rg.top_row == 2)
-            rt = bp_row(p.lat0_bp + (lattice_node(p.q, 0, p.ny) * (90 - p.lat0_bp)) / (double)p.ny, p.rp);
-        else
-            rt = p.row_tab[(long)M * p.ny + 1];
-        eval_lattice_row<N, MODE>(p, rt, col, sx, sy, rp2x4, rp2, cur);
+        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, sx, sy, rp2x4, rp2, cur);
         if (cell_lane) p.dxq[rg.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
         return;
     }
@@ -488,7 +479,7 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long bx
 
 template <int N, int MODE>
 __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams p, QuadRange rg) {
-    bipolar_quad_body<N, MODE>(p, rg, blockIdx.x, blockIdx.y);
+    bipolar_quad_body<N, MODE>(p, rg, (long)blockIdx.x * QS_WAVES + (threadIdx.x >> 6), blockIdx.y);
 }
 
 // Literal re-evaluation (bp_point, OGG:41-95 operation for operation) of the cells the guard handed over: half a wave per
@@ -496,14 +487,23 @@ __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams 
 // in the reference's order; overwrites the cell's dxq, dyq, daq (and dyq[.][nx] for the last cell of a row).  A cell is
 // re-evaluated iff one of ITS points is guarded, which depends on the cell alone: the result does not depend on tiling or
 // banding.
+//
+// The same launch evaluates dxq[ny][:] (the exact j = ny lattice row, literal as well) in its first n_top workgroups, one
+// strip each; top.top_row must be 1.
 template <int N>
-__global__ __launch_bounds__(64) void bipolar_quad_fixup_kernel(QuadParams p) {
+__global__ __launch_bounds__(64) void bipolar_quad_tail_kernel(QuadParams p, QuadRange top, unsigned n_top, unsigned do_fixup) {
     constexpr int M = N - 1;
     __shared__ double sdx[64], sdy[64];
+    if (blockIdx.x < n_top) {
+        bipolar_quad_body<N, QM_LITERAL>(p, top, blockIdx.x, 0);
+        return;
+    }
+    if (!do_fixup) return;
+    const unsigned bid = blockIdx.x - n_top, nblk = gridDim.x - n_top;
     const unsigned count = *p.fix_count;
     const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
     const int jj = (q < N * N) ? q / N : 0, ii = (q < N * N) ? q % N : 0;
-    for (unsigned k0 = blockIdx.x * 2; k0 < count; k0 += gridDim.x * 2) {  // wave-uniform trip count
+    for (unsigned k0 = bid * 2; k0 < count; k0 += nblk * 2) {  // wave-uniform trip count
         const unsigned k = k0 + half;
         const bool have = k < count;
         const unsigned lin = have ? p.fix_list[k] : 0u;
@@ -667,6 +667,17 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
 
 constexpr unsigned FIXUP_BLOCKS = 2048;
 
+// fix-up of the guarded cells and / or the j = ny row of dxq, whichever this band has
+template <int N>
+int launch_quad_tail(const QuadPlan& q, hipStream_t s) {
+    const unsigned n_top = q.has_top ? (unsigned)((q.p.nx + QS_CELLS - 1) / QS_CELLS) : 0u;
+    const unsigned n_fix = q.has_guard ? FIXUP_BLOCKS : 0u;
+    if (n_top + n_fix == 0) return OGG_OK;
+    bipolar_quad_tail_kernel<N><<<n_top + n_fix, 64, 0, s>>>(q.p, q.top, n_top, q.has_guard ? 1u : 0u);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
+
 template <int N>
 int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
     // workspace (row/column tables, fix-up counter and list): the caller's (graph-capturable: no allocation at all), or from
@@ -689,13 +700,8 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, 
     if (q.has_guard) {
         bipolar_quad_kernel<N, QM_GUARD><<<dim3(q.gx, q.guard.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.guard);
         OGG_LAUNCH_CHECK();
-        bipolar_quad_fixup_kernel<N><<<FIXUP_BLOCKS, 64, 0, s>>>(q.p);
-        OGG_LAUNCH_CHECK();
     }
-    if (q.has_top) {
-        bipolar_quad_kernel<N, QM_LITERAL><<<dim3(q.gx, 1), 64 * QS_WAVES, 0, s>>>(q.p, q.top);
-        OGG_LAUNCH_CHECK();
-    }
+    if (int e = launch_quad_tail<N>(q, s)) return e;
     if (!ext_ws) OGG_HIP_CHECK(hipFreeAsync(ws, s));
     return OGG_OK;
 }

@@ -5,9 +5,9 @@
 // on separate streams -- which costs 10-20 us of cross-queue signalling per dependency, as much as the kernels themselves
 // once the grid is split over 8 GPUs -- each launch carries workgroups of BOTH kinds, told apart by their workgroup index:
 //
-//   launch A:  lat-lon row strips [0, s1)  |  j = ny row of the quadrature (literal)  |  row/column tables  |  cap mesh + angle
+//   launch A:  lat-lon row strips [0, s1)  |  row/column tables of the quadrature  |  cap mesh + angle
 //   launch B:  lat-lon row strips [s1, S)  |  quadrature strips with the guard  |  quadrature strips without
-//   launch C:  literal fix-up of the cells the guard handed over
+//   launch C:  literal fix-up of the cells the guard handed over  |  j = ny row of the quadrature (literal)
 //
 // The lat-lon workgroups come first in the index space (they are resident from the start and walk their strips grid-stride
 // while the compute workgroups stream through the remaining slots); s1 splits the lat-lon strips in proportion to the
@@ -38,8 +38,7 @@ struct PassAParams {
     MeshParams mesh;
     long mesh_gx, n_mesh;   // mesh workgroups: mesh_gx column tiles x row tiles
     QuadParams q;
-    QuadRange top;
-    long n_top, n_tab;      // workgroups of the j = ny row and of the tables
+    long n_tab;             // workgroups of the tables
 };
 
 template <int N>
@@ -51,17 +50,12 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
         return;
     }
     b -= a.share.n_wg;
-    if (b < a.n_top) {
-        bipolar_quad_body<N, QM_LITERAL>(a.q, a.top, b, 0);
-        return;
-    }
-    b -= a.n_top;
     if (b < a.n_tab) {
         bipolar_tables_body<N>(a.q, b);
         return;
     }
     b -= a.n_tab;
-    if (b < a.n_mesh) bipolar_mesh_body(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
+    if (b < a.n_mesh) bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
 }
 
 struct PassBParams {
@@ -82,11 +76,11 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     }
     b -= a.share.n_wg;
     if (b < a.n_guard) {
-        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, b % a.gx, b / a.gx);
+        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
         return;
     }
     b -= a.n_guard;
-    if (b < a.n_fast) bipolar_quad_body<N, QM_FAST>(a.q, a.fast, b % a.gx, b / a.gx);
+    if (b < a.n_fast) bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
 }
 
 long env_long(const char* name, long dflt) {
@@ -132,9 +126,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         p.dxq = cap->dx, p.dyq = cap->dy, p.daq = cap->area, p.q = make_nodes(N);
         if (int e = plan_quad<N>(p, cap->n_pt_rows, cap->n_cell_rows, guard_k, cap->workspace, cap->workspace_bytes, qp)) return e;
         A.q = qp.p, B.q = qp.p;
-        A.top = qp.top;
-        A.top.top_row = 2;  // the tables are written by this same launch
-        A.n_top = qp.has_top ? qp.gx : 0, A.n_tab = tables_blocks<N>(qp.p);
+        A.n_tab = tables_blocks<N>(qp.p);
         B.gx = qp.gx;
         B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.gx * qp.guard.gy : 0;
         B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.gx * qp.fast.gy : 0;
@@ -153,7 +145,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         s1 = s1 < 0 ? 0 : (s1 > n_strips_ll ? n_strips_ll : s1);
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap);
-    const long na = A.share.n_wg + A.n_top + A.n_tab + A.n_mesh;
+    const long na = A.share.n_wg + A.n_tab + A.n_mesh;
     if (na > 0) {
         pass_a_kernel<N><<<(unsigned)na, PASS_TX, 0, st>>>(A);
         OGG_LAUNCH_CHECK();
@@ -163,10 +155,9 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         const unsigned nb = (unsigned)(B.share.n_wg + B.n_guard + B.n_fast);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
         OGG_LAUNCH_CHECK();
-        if (qp.has_guard) {
-            bipolar_quad_fixup_kernel<N><<<FIXUP_BLOCKS, 64, 0, st>>>(qp.p);
-            OGG_LAUNCH_CHECK();
-        }
+    }
+    if (have_quad) {
+        if (int e = launch_quad_tail<N>(qp, st)) return e;
     }
     return OGG_OK;
 }

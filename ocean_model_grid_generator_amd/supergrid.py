@@ -105,16 +105,18 @@ class SupergridPlan(object):
         bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=lat0_bp, lon_bp=self.lon0,
                          rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
         # Row cost for the band split of the cap.  The quadrature guards its algebraic per-point form near the two pole points
-        # (csrc/ogg_bipolar.hip, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K)) carry the guard (1.35x a
-        # plain row, measured at 1/8 degree: mesh + quadrature), and those above acos(1/sqrt(K)) also contain the cells the
-        # literal fix-up re-evaluates (2.6x).
+        # (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K)) carry the guard (1.3x a
+        # plain row), and those above acos(1/sqrt(K)) also contain the cells the literal fix-up re-evaluates (2.0x) -- weights
+        # that equalise the measured per-rank times of the fused pass at 1/8 degree over 2, 4 and 8 ranks
+        # (scripts/rank_sweep.py; OGG_BP_ROW_COST="fix,guard" overrides them).
         import os
         K = float(os.environ.get("OGG_BP_GUARD_K", "1000"))
         if K > 4.0:
             lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
             guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
             fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
-            bp.row_cost = np.where(lat_rows >= fix_lat, 2.6, np.where(lat_rows >= guard_lat, 1.35, 1.0))
+            w_fix, w_guard = (float(v) for v in os.environ.get("OGG_BP_ROW_COST", "2.0,1.3").split(","))
+            bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
         # Southern Ocean (OGG:1080-1103)
         lat0_SO = -78.0
         lenlat_SO = latUp_SO - lat0_SO

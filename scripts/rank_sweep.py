@@ -1,0 +1,39 @@
+"""Time every rank's share of a W-way band split on ONE GPU, one after the other (rehearsal of the multi-GPU run).
+
+usage: python scripts/rank_sweep.py --world 8 [--workload r8] [--cost 2.6,1.35 ...]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ocean_model_grid_generator_amd import supergrid  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--workload", default="r8")
+ap.add_argument("--cost", nargs="*", default=["2.6,1.35"])
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--launch", default="pass")
+args = ap.parse_args()
+for cost in args.cost:
+    os.environ["OGG_BP_ROW_COST"] = cost
+    plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
+    ts = []
+    for r in range(args.world):
+        sg = supergrid.Supergrid(plan, rank=r, world=args.world, device="cuda:0", halo="recompute")
+        sg.launch, sg.overlap = args.launch, False
+        for _ in range(5):
+            sg.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sg.run_pass()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / args.steps * 1e3)
+        del sg
+    print("world %d cost %s: max %.4f ms  [%s]" % (args.world, cost, max(ts), " ".join("%.4f" % t for t in ts)), flush=True)
