@@ -412,11 +412,29 @@ class Supergrid(object):
         the caller's stream before returning.  Under graph capture this becomes a forked graph."""
         torch = self.torch
         if self.latlon == "fused" and self.launch == "pass":
+            dp = [s for s in self.plan.subs if s.kind == "dpole" and self.buf[s.name]["n"] > 0]
+            side = None
+            if dp and self.overlap and self.device.type == "cuda":  # the displaced-pole cap next to the pass, on one side stream
+                main = torch.cuda.current_stream(self.device)
+                if not self._side:
+                    self._side = [torch.cuda.Stream(self.device)]
+                side = self._side[0]
+                fork = torch.cuda.Event()
+                fork.record(main)
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    self.phase_a(kinds=("dpole",))
+                    self.phase_b(kinds=("dpole",))
+                    join = torch.cuda.Event()
+                    join.record(side)
             self.tripolar_pass()
             if self.plan.skip_metrics:
                 self.phase_b(kinds=("mercator", "latlon", "bipolar"))  # the -1 fill of OGG:1327-1329
-            self.phase_a(kinds=("dpole",))
-            self.phase_b(kinds=("dpole",))
+            if side is not None:
+                main.wait_event(join)
+            elif dp:
+                self.phase_a(kinds=("dpole",))
+                self.phase_b(kinds=("dpole",))
             return
         if self.latlon != "fused" or self.device.type != "cuda" or not self.overlap:
             self.phase_a()
