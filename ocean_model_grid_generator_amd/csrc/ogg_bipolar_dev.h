@@ -32,7 +32,7 @@ struct BpCol {       // depends on the (fractional) column index only
 
 OGG_DEV BpRow bp_row(double phig_in, double rp) {
     BpRow r;
-    const double phig = 90 - 2 * atan(tan(0.5 * (90 - phig_in) * kPi180) / rp) / kPi180;  // OGG:41
+    const double phig = 90 - div_pi180(2 * atan(tan(0.5 * (90 - phig_in) * kPi180) / rp));  // OGG:41
     const double pr = phig * kPi180;
     r.sphig = sin(pr);
     const double t = tan(pr);
@@ -62,7 +62,7 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
     const double chic = acos(A);
     const double t = tan(chic / 2);
     const double rpt = rp * t;
-    phis = 90 - 2 * atan(rpt) / kPi180;
+    phis = 90 - div_pi180(2 * atan(rpt));
     const double rden2 = 1.0 / (1 + rpt * rpt);
     const double M_inv = rp * (1 + t * t) * rden2;
     const double cp = cos(phis * kPi180);
@@ -99,7 +99,7 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
     const double A = c.sinla * r.sphig;
     const double p1 = 1 + A, m1 = 1 - A;
     const double P = 1.0 + ab;                    // 1/rden
-    const double D = p1 + rp2 * m1;
+    const double D = fma(rp2, m1, p1);
     const double inv = rcp_nr(P * D);             // one reciprocal for both quotients
     const double rden = D * inv, E = P * inv;
     const double MM = rp2x4 * (E * E);            // M_inv^2
@@ -107,8 +107,8 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
     const double ccrr = cc * (rden * rden);
     const double Mr = MM * rden;
     const double t1j = ccrr * (aa1 * bb1), t1i = ccrr * (1 + b);
-    hj2 = t1j + Mr * a1;
-    hi2 = t1i + Mr * ab;
+    hj2 = fma(Mr, a1, t1j);
+    hi2 = fma(Mr, ab, t1i);
     // (the |beta2_inv| > HUGE case of OGG:86,94 only occurs on the exact j = ny row, which never takes this path)
     //
     // Exactness guard.  The literal sequence rounds phis = 90 - 2 atan(rp t)/PI_180 to a multiple of ulp(90) before taking
@@ -128,7 +128,7 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
 OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double rden, double lamg, double lon_bp) {
     double B = c.sinla * sqrt(rden);
     if (fabs(r.beta2_inv) > kHuge) B = 0.0;
-    double lamc = asin(B) / kPi180;
+    double lamc = div_pi180(asin(B));
     const double dl = lamg - lon_bp;
     if ((dl > 90) && (dl <= 180)) lamc = 180 - lamc;
     if ((dl > 180) && (dl <= 270)) lamc = 180 + lamc;
@@ -208,8 +208,10 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
         const double rden = 1.0 / (1.0 + c.alpha2 * row.beta2_inv);                    // OGG:47
         const double lam = bp_lams(row, c, rden, lamg, lon_bp);
         const double A = c.sinla * row.sphig;
-        const double t = sqrt((1 - A) / (1 + A));                                      // == tan(acos(A)/2), OGG:69-70
-        const double phi = 90 - 2 * atan(rp * t) / kPi180;
+        const double m1 = 1 - A, p1 = 1 + A;
+        const double t = (m1 > 0.0) ? m1 * rsqrt_nr(m1 * p1) : 0.0;                    // sqrt((1-A)/(1+A)) == tan(acos(A)/2), OGG:69-70
+        const double u = rp * t;
+        const double phi = 90 - div_pi180(2 * atan(u));
         if (out) {
             lams[jl * ni1 + i] = lam;
             phis[jl * ni1 + i] = phi;
@@ -223,7 +225,9 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
         if (angle) {                                                                   // OGG:725-728
             const double xl = __shfl_up(lam, 1), xr = __shfl_down(lam, 1);
             const double yl = __shfl_up(phi, 1), yr = __shfl_down(phi, 1);
-            const double cy = cos(phi * kPi180);
+            // cos(phi PI/180) = sin(2 atan u) = 2u/(1+u^2): differs from the cosine of the ROUNDED phi by < 7e-15/(90-phi) relative,
+            // three orders below what the last-ulp differences of lam, phi do to their finite differences here
+            const double cy = (2 * u) / (1 + u * u);
             double a;
             if (i == 0)
                 a = atan2(yr - phi, (xr - lam) * cy);
@@ -231,7 +235,7 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
                 a = atan2(phi - yl, (lam - xl) * cy);
             else
                 a = atan2(yr - yl, (xr - xl) * cy);
-            if (out) angle[jl * ni1 + i] = a / kPi180;
+            if (out) angle[jl * ni1 + i] = div_pi180(a);
         }
     }
 }
@@ -342,8 +346,9 @@ constexpr int QS_WAVES = 4;    // strips per workgroup
 
 template <int N, int MODE>
 struct RowEval {
-    double dx[N];  // dx at this lane's columns ii = 0..N-2 and, in [N-1], at the right edge (from lane+1)
-    double dy[N];
+    double dx[N];  // dx at this lane's columns ii = 0..N-2 and, in [N-1], at the right edge (from lane+1); only if want_dx
+    double dy0;    // dy at ii = 0 (the lane's left cell edge)
+    double pr[N];  // dx*dy at the same N columns (OGG:178)
     int guarded;   // any of these N points failed the exactness guard (always 0 on the literal path)
 };
 
@@ -351,7 +356,9 @@ constexpr int QM_FAST = 0, QM_GUARD = 1, QM_LITERAL = 2;  // per-point method of
 
 template <int N, int MODE>
 OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* col, double sx, double sy, double rp2x4, double rp2,
-                              RowEval<N, MODE>& o) {  // r: factors of the lattice row (wave-uniform)
+                              bool want_dx, RowEval<N, MODE>& o) {  // r: factors of the lattice row; r, want_dx wave-uniform
+    // want_dx: the row is the bottom edge of a cell row, whose dx feeds dxq (OGG:183).  On the other rows the algebraic path
+    // needs dx only inside the product dx*dy, which it then takes as sqrt(hi2*hj2) -- one square root instead of two.
     constexpr int M = N - 1;
     constexpr bool FAITHFUL = (MODE == QM_LITERAL);
     if (FAITHFUL) {
@@ -372,8 +379,9 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
 #pragma unroll
             for (int k = 0; k < M; ++k) {
                 o.dx[k] = (ii == k) ? dx : o.dx[k];
-                o.dy[k] = (ii == k) ? dy : o.dy[k];
+                o.pr[k] = (ii == k) ? dx * dy : o.pr[k];                           // OGG:178
             }
+            if (ii == 0) o.dy0 = dy;
         }
     } else {
         const double bb1 = r.beta2_inv * (1 + r.beta2_inv), nsy = r.N_inv * sy;
@@ -385,16 +393,23 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
             const bool g = bp_point_fast<MODE == QM_GUARD>(r, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, p.guard_k, hi2, hj2);
             if (ii == 0) g_first = g;
             g_any |= (int)g;
-            o.dx[ii] = sqrt_nr(hi2) * sx;
             // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): sqrt_nr(0) would be 0 * inf
-            o.dy[ii] = (hj2 > 0.0) ? sqrt_nr(hj2) * nsy : 0.0;
+            if (ii == 0 || want_dx) {
+                const double dx = sqrt_nr(hi2) * sx;
+                const double dy = (hj2 > 0.0) ? sqrt_nr(hj2) * nsy : 0.0;
+                o.dx[ii] = dx;
+                o.pr[ii] = dx * dy;
+                if (ii == 0) o.dy0 = dy;
+            } else {
+                o.pr[ii] = (hj2 > 0.0) ? sqrt_nr(hi2 * hj2) * (sx * nsy) : 0.0;
+            }
         }
         o.guarded = 0;
         if (MODE == QM_GUARD) o.guarded = g_any | __shfl_down(g_first, 1);  // the right edge is lane+1's first column
     }
     if (FAITHFUL) o.guarded = 0;
-    o.dx[M] = __shfl_down(o.dx[0], 1);
-    o.dy[M] = __shfl_down(o.dy[0], 1);
+    if (FAITHFUL || want_dx) o.dx[M] = __shfl_down(o.dx[0], 1);
+    o.pr[M] = __shfl_down(o.pr[0], 1);
 }
 
 template <int N, int MODE>
@@ -417,13 +432,13 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
     const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
     RowEval<N, MODE> cur;
     if (rg.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
-        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, sx, sy, rp2x4, rp2, cur);
+        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, sx, sy, rp2x4, rp2, true, cur);
         if (cell_lane) p.dxq[rg.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
         return;
     }
     const long r0 = rg.row_begin + by * rg.rows_per_chunk;
     const long r1 = (r0 + rg.rows_per_chunk < rg.row_end) ? r0 + rg.rows_per_chunk : rg.row_end;
-    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, sx, sy, rp2x4, rp2, cur);
+    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, sx, sy, rp2x4, rp2, true, cur);
     for (long c = r0; c < r1; ++c) {
         const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
         int guarded = cur.guarded;                                          // bottom-edge row (carried)
@@ -435,23 +450,27 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
 #pragma unroll(N <= 3 ? N : 1)
         for (int jj = 0; jj < N; ++jj) {
             if (jj > 0) {
-                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, sx, sy, rp2x4, rp2, cur);
+                // the top row of this cell row is the bottom row of the next one (not needed past the end of the chunk)
+                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, sx, sy, rp2x4, rp2, jj == M && c + 1 < r1, cur);
                 guarded |= cur.guarded;
             }
             const double wj = quad_weight_1d<N>(jj);
 #pragma unroll
             for (int ii = 0; ii < N; ++ii) {
-                const double pr = cur.dx[ii] * cur.dy[ii];                  // OGG:178
+                const double pr = cur.pr[ii];
                 if (N <= 3) {
 #pragma unroll
                     for (int k = 0; k < N * N; ++k)
                         if (N <= 3 && k == jj * N + ii) y2[(N <= 3) ? k : 0] = pr;
                 } else {
-                    ysum = ysum + (quad_weight_1d<N>(ii) * wj) * pr;        // OGG:244 / 252
+                    if (FAITHFUL)
+                        ysum = ysum + (quad_weight_1d<N>(ii) * wj) * pr;    // OGG:244 / 252
+                    else
+                        ysum = fma(quad_weight_1d<N>(ii) * wj, pr, ysum);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < N; ++k) dyc[k] = (jj == k) ? cur.dy[0] : dyc[k];
+            for (int k = 0; k < N; ++k) dyc[k] = (jj == k) ? cur.dy0 : dyc[k];
         }
         // cur now holds lattice row (c, N-1) == (c+1, 0): the bottom row of the next cell row
         const long out_r = c - p.j0;

@@ -88,7 +88,7 @@ OGG_DEV void dp_point(double r, cplx ep, const DpConst& c, double& lam_raw, doub
     const cplx w = cdiv(num, den);
     lam_raw = atan2(w.im, w.re) * k180Pi;  // np.angle(deg=True)
     const double rw = cabs_np(w);
-    phi = -90 + atan(rw * c.r_joint) / kPi180;
+    phi = -90 + div_pi180(atan(rw * c.r_joint));
 }
 
 // OGG:527-532 for point0 = (lam0, phi0), point1 = (lam1, phi1) in degrees

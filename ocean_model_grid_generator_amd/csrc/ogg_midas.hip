@@ -93,7 +93,7 @@ OGG_DEV double angle_of(const RowVals& v, long i, long ni1) {
         a = atan2(v.yc - v.yl, (v.xc - v.xl) * c);
     else
         a = atan2(v.yr - v.yl, (v.xr - v.xl) * c);
-    return a / kPi180;
+    return div_pi180(a);
 }
 
 template <bool METRICS, bool AREAFIX>
