@@ -7,7 +7,7 @@ extern "C" int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band
     long points = 0;
     if (int e = plan_latlon(n_bands, bands, ni1, lon0, lenlon, Re, metrics, p, points)) return e;
     if (p.n_bands == 0) return OGG_OK;
-    const long gx = (ni1 + LF_TX - 1) / LF_TX;
+    const long gx = latlon_gx(ni1);
     // Resident workgroups: ~115 (measured: 92 already slow the kernel by 20 %, 69 by 60 %) saturate the HBM write path on a large launch (measured), which leaves the CUs to a
     // concurrent VALU-bound kernel; small launches are latency-bound and take the whole chip.
     long max_wg = points >= 8000000 ? 115 : (points >= 2000000 ? 512 : 2048);

@@ -54,29 +54,100 @@ OGG_DEV double axis_lat(const ogg_latlon_band& b, long k, double Ni) {
     return b.lat1d[k];
 }
 
+// column-only quantities (OGG:696, 713, 725-727) of column i
+struct ColScalars {
+    double lon_c, dlam, hdlam, xdiff;
+};
+
+OGG_DEV ColScalars column_scalars(const FusedParams& p, long i) {
+    const long ni1 = p.ni1, ni = ni1 - 1;
+    const long ic = (i < ni1) ? i : ni;
+    ColScalars c;
+    c.lon_c = p.lon0 + ((double)ic * p.lenlon) / p.Ni;
+    const double lon_r = p.lon0 + ((double)((ic + 1 < ni1) ? ic + 1 : ic) * p.lenlon) / p.Ni;
+    const double lon_l = p.lon0 + ((double)((ic > 0) ? ic - 1 : 0) * p.lenlon) / p.Ni;
+    c.dlam = mdist(lon_r, c.lon_c) * kPi180;
+    c.hdlam = 0.5 * (c.dlam + c.dlam);
+    if (i == 0)
+        c.xdiff = lon_r - c.lon_c;
+    else if (i == ni)
+        c.xdiff = c.lon_c - lon_l;
+    else
+        c.xdiff = lon_r - lon_l;
+    return c;
+}
+
+// Two adjacent columns in one 16-byte store.  Rows of odd length are only 8-byte aligned; pairing the columns per row so
+// that every store is 16-byte aligned was tried and is SLOWER: what limits a lat-lon workgroup is the number of
+// instructions per row, not the store width.
+typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
+
+// FULL: both columns exist (one unconditional 16-byte store); else each one on its own flag
+template <bool FULL>
+OGG_DEV void store2(double* q, double a, double b, bool first, bool second) {
+    if (FULL) {
+        dbl2 v;
+        v.x = a, v.y = b;
+        *reinterpret_cast<dbl2*>(q) = v;
+    } else {
+        if (first) q[0] = a;
+        if (second) q[1] = b;
+    }
+}
+
+// angle_x of a lat-lon mesh: atan2(+0, pa)/PI_180 with pa = (lon difference) cos(lat).  IEEE atan2(+0, pa) is +0 for pa > 0
+// or pa = +0 and pi for pa < 0 or pa = -0, i.e. it follows the SIGN BIT of pa; NaN propagates.  No branch.
+OGG_DEV double latlon_angle(double pa) {
+    const double r = (__double2hiint(pa) < 0) ? kPi / kPi180 : 0.0 / kPi180;
+    return (pa != pa) ? pa : r;
+}
+
+// The rows js .. js+nrows-1 of one band for this thread's two columns.  FULL: both columns exist and both have a right
+// neighbour -- every thread but the last one or two of a row -- so the loop has no per-lane branch: what limits a lat-lon
+// workgroup is the instruction count per row, not the store width.
+template <bool FULL>
+OGG_DEV void latlon_rows(const FusedParams& p, const ogg_latlon_band& b, const RowScalars* s_row, long js, int nrows, long n_cell_rows,
+                         long i0, const ColScalars& c0, const ColScalars& c1) {
+    const long ni1 = p.ni1, ni = ni1 - 1;
+    const bool pt1 = i0 + 1 < ni1, ce0 = i0 < ni;  // !FULL only: second point column exists; first column has a right neighbour
+    double* __restrict__ px = b.x + (js * ni1 + i0);
+    double* __restrict__ py = b.y + (js * ni1 + i0);
+    double* __restrict__ pa = b.angle + (js * ni1 + i0);
+    double* __restrict__ pdx = b.dx + (js * ni + i0);
+    double* __restrict__ pdy = b.dy + (js * ni1 + i0);
+    double* __restrict__ par = b.area + (js * ni + i0);
+    for (int r = 0; r < nrows; ++r) {
+        const long j = js + r;
+        const RowScalars rs = s_row[r];
+        store2<FULL>(px, c0.lon_c, c1.lon_c, true, pt1);
+        store2<FULL>(py, rs.lat, rs.lat, true, pt1);
+        store2<FULL>(pa, latlon_angle(c0.xdiff * rs.cl), latlon_angle(c1.xdiff * rs.cl), true, pt1);
+        if (p.metrics) {
+            // dx = Re sqrt(0 + t^2) with t = dlam cos(lv): sqrt(RN(t^2)) == |t| in binary floating point (no over/underflow here)
+            store2<FULL>(pdx, p.Re * fabs(c0.dlam * rs.cl), p.Re * fabs(c1.dlam * rs.cl), ce0, false);
+            if (j < n_cell_rows) {
+                store2<FULL>(pdy, rs.dy, rs.dy, true, pt1);
+                const double ds = s_row[r + 1].sl - rs.sl;
+                store2<FULL>(par, p.Re2 * (c0.hdlam * ds), p.Re2 * (c1.hdlam * ds), ce0, false);
+            }
+        }
+        px += ni1, py += ni1, pa += ni1, pdy += ni1;
+        pdx += ni, par += ni;
+    }
+}
+
+constexpr int LF_COLS = 2 * LF_TX;  // columns per workgroup: every thread owns two adjacent columns
+inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
+
 // workgroup bx of the column tiles; it takes the row strips strip_lo + by, + gy, ... < strip_hi.  s_row: LF_ROWS + 1 entries.
 OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long bx, long by, long gy, long strip_lo, long strip_hi) {
     const int tid = threadIdx.x;
-    const long i = bx * LF_TX + tid;
+    const long i0 = (bx * LF_TX + tid) * 2;
     const long ni1 = p.ni1, ni = ni1 - 1;
-    // column-only quantities (OGG:696, 713, 725-727)
-    const long ic = (i < ni1) ? i : ni;
-    const double lon_c = p.lon0 + ((double)ic * p.lenlon) / p.Ni;
-    const double lon_r = p.lon0 + ((double)((ic + 1 < ni1) ? ic + 1 : ic) * p.lenlon) / p.Ni;
-    const double lon_l = p.lon0 + ((double)((ic > 0) ? ic - 1 : 0) * p.lenlon) / p.Ni;
-    const double dlam = mdist(lon_r, lon_c) * kPi180;
-    const double hdlam = 0.5 * (dlam + dlam);
-    double xdiff;
-    if (i == 0)
-        xdiff = lon_r - lon_c;
-    else if (i == ni)
-        xdiff = lon_c - lon_l;
-    else
-        xdiff = lon_r - lon_l;
-    const bool has_r = i < ni;
-    const double pi_deg = kPi / kPi180;
+    const ColScalars c0 = column_scalars(p, i0), c1 = column_scalars(p, i0 + 1);
+    const bool full = i0 + 1 < ni;  // both columns exist and have a right neighbour
     // Row strips of all bands are taken grid-stride: the launch caps the number of resident workgroups (an HBM-write-bound
-    // kernel needs only a few waves per SIMD) so that a VALU-bound kernel running on another stream can share the CUs.
+    // kernel needs only a few waves per SIMD) so that VALU-bound workgroups can share the CUs.
     for (long strip = strip_lo + by; strip < strip_hi; strip += gy) {
         int bi = 0;
         while (bi + 1 < p.n_bands && strip >= p.strip0[bi + 1]) ++bi;
@@ -106,27 +177,10 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long bx,
             }
         }
         __syncthreads();
-        if (i < ni1) {
-            for (int r = 0; r < nrows; ++r) {
-                const long j = js + r;
-                const RowScalars rs = s_row[r];
-                b.x[j * ni1 + i] = lon_c;
-                b.y[j * ni1 + i] = rs.lat;
-                const double pa = xdiff * rs.cl;
-                const bool zero = (pa > 0.0) || (pa == 0.0 && !signbit(pa));
-                b.angle[j * ni1 + i] = (pa != pa) ? pa : (zero ? 0.0 / kPi180 : pi_deg);
-                if (p.metrics) {
-                    if (has_r) {
-                        const double t = dlam * rs.cl;
-                        b.dx[j * ni + i] = p.Re * sqrt(0.0 + t * t);
-                    }
-                    if (j < n_cell_rows) {
-                        b.dy[j * ni1 + i] = rs.dy;
-                        if (has_r) b.area[j * ni + i] = p.Re2 * (hdlam * (s_row[r + 1].sl - rs.sl));
-                    }
-                }
-            }
-        }
+        if (full)
+            latlon_rows<true>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
+        else if (i0 < ni1)  // the last column (ni1 odd) or the last pair (no dx / area in its second column)
+            latlon_rows<false>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
         __syncthreads();  // the row table is rewritten by the next strip
     }
 }
@@ -157,7 +211,7 @@ inline int plan_latlon(int n_bands, const ogg_latlon_band* bands, long ni1, doub
         points += b.n_pt_rows * ni1;
     }
     if (p.n_bands == 0) return OGG_OK;
-    const long gx = (ni1 + LF_TX - 1) / LF_TX;
+    const long gx = latlon_gx(ni1);
     long rpb = (total_rows * gx + 2047) / 2048;  // aim at >= 2048 row strips x column tiles
     rpb = rpb < 4 ? 4 : (rpb > LF_ROWS ? LF_ROWS : rpb);
     p.strip0[0] = 0;

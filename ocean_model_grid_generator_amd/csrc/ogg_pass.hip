@@ -90,13 +90,13 @@ long env_long(const char* name, long dflt) {
 
 LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone) {
     LatlonShare s{};
-    s.gx = (ni1 + LF_TX - 1) / LF_TX;
+    s.gx = latlon_gx(ni1);
     s.strip_lo = lo, s.strip_hi = hi;
     if (hi <= lo) return s;
     // resident lat-lon workgroups: enough to keep the HBM write path busy and not more, so that the VALU-bound workgroups of
     // the same launch get the remaining wave slots; a launch without compute workgroups takes the whole chip
     const long points = (hi - lo) * ll.rows_per_block * ni1;
-    long max_wg = alone ? 2048 : (points >= 4000000 ? env_long("OGG_PASS_LL_WG", 115) : env_long("OGG_PASS_LL_WG_SMALL", 184));
+    long max_wg = alone ? 2048 : (points >= 4000000 ? env_long("OGG_PASS_LL_WG", 84) : env_long("OGG_PASS_LL_WG_SMALL", 120));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
     s.gy = gy < 1 ? 1 : gy;
@@ -105,7 +105,12 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
 }
 
 template <int N>
-int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, hipStream_t st) {
+int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, hipEvent_t* ev, hipStream_t st) {
+    // ev: NULL, or 4 events recorded before launch A and after launches A, B and C (bench.py times the launches with them)
+    auto mark = [&](int k) -> int {
+        if (ev) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
+        return OGG_OK;
+    };
     const long n_strips_ll = ll.n_bands ? ll.strip0[ll.n_bands] : 0;
     const bool have_cap = cap && cap->n_pt_rows > 0;
     const bool have_quad = have_cap && metrics;
@@ -146,26 +151,29 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap);
     const long na = A.share.n_wg + A.n_tab + A.n_mesh;
+    if (int e = mark(0)) return e;
     if (na > 0) {
         pass_a_kernel<N><<<(unsigned)na, PASS_TX, 0, st>>>(A);
         OGG_LAUNCH_CHECK();
     }
+    if (int e = mark(1)) return e;
     if (launch_b) {
         B.share = make_share(ll, s1, n_strips_ll, ni1, false);
         const unsigned nb = (unsigned)(B.share.n_wg + B.n_guard + B.n_fast);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
         OGG_LAUNCH_CHECK();
     }
+    if (int e = mark(2)) return e;
     if (have_quad) {
         if (int e = launch_quad_tail<N>(qp, st)) return e;
     }
-    return OGG_OK;
+    return mark(3);
 }
 
 }  // namespace
 
-extern "C" int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
-                                     int metrics, const ogg_bipolar_band* cap, void* stream) {
+extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
+                                            int metrics, const ogg_bipolar_band* cap, void** events4, void* stream) {
     FusedParams ll;
     long points = 0;
     if (int e = plan_latlon(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, ll, points)) return e;
@@ -188,10 +196,16 @@ extern "C" int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon
         }
     }
     hipStream_t st = ogg::as_stream(stream);
+    hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(events4);
     switch (order) {
-        case 2: return launch_pass<2>(ll, ni1, metrics, cap, st);
-        case 3: return launch_pass<3>(ll, ni1, metrics, cap, st);
-        case 4: return launch_pass<4>(ll, ni1, metrics, cap, st);
-        default: return launch_pass<5>(ll, ni1, metrics, cap, st);
+        case 2: return launch_pass<2>(ll, ni1, metrics, cap, ev, st);
+        case 3: return launch_pass<3>(ll, ni1, metrics, cap, ev, st);
+        case 4: return launch_pass<4>(ll, ni1, metrics, cap, ev, st);
+        default: return launch_pass<5>(ll, ni1, metrics, cap, ev, st);
     }
+}
+
+extern "C" int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
+                                     int metrics, const ogg_bipolar_band* cap, void* stream) {
+    return ogg_tripolar_pass_events_dev(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, nullptr, stream);
 }

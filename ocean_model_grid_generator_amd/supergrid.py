@@ -188,6 +188,7 @@ class Supergrid(object):
         # "pass": lat-lon sub-grids + bipolar cap through ogg_tripolar_pass_dev (three launches on one stream, the two kinds
         # of work sharing each launch); "kernels": one call per sub-grid and phase, on side streams when `overlap` is set
         self.launch = "kernels"
+        self.pass_events = None  # a list: tripolar_pass() times its launches into it
         self._side = None
         self.buf = {}
         self.timings = {}
@@ -291,8 +292,33 @@ class Supergrid(object):
                 cap.dy = b["dy"].data_ptr() if b["n_cell"] else None
                 cap.area = b["area"].data_ptr() if b["n_cell"] else None
                 cap.workspace, cap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
-        self._timed("tripolar_pass", lambda: L.call("ogg_tripolar_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re,
-                                                    0 if p.skip_metrics else 1, ctypes.byref(cap) if cap is not None else None, st))
+        capref = ctypes.byref(cap) if cap is not None else None
+        if self.pass_events is None:
+            L.call("ogg_tripolar_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, st)
+            return
+        # per-launch timing: four HIP events recorded by the library around its three launches
+        evs = (ctypes.c_void_p * 4)()
+        for k in range(4):
+            e = ctypes.c_void_p()
+            L.call("ogg_event_create", ctypes.byref(e))
+            evs[k] = e
+        L.call("ogg_tripolar_pass_events_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, evs, st)
+        self.pass_events.append(evs)
+
+    def pass_launch_times_ms(self):
+        """Mean duration of the three launches of the fused pass over the passes run since `pass_events = []`."""
+        L.call("ogg_stream_synchronize", self._stream())
+        tot = [0.0, 0.0, 0.0]
+        for evs in self.pass_events:
+            for k in range(3):
+                ms = ctypes.c_float()
+                L.call("ogg_event_elapsed_ms", evs[k], evs[k + 1], ctypes.byref(ms))
+                tot[k] += ms.value
+            for k in range(4):
+                L.call("ogg_event_destroy", evs[k])
+        n = max(len(self.pass_events), 1)
+        self.pass_events = []
+        return {"pass_a": tot[0] / n, "pass_b": tot[1] / n, "pass_tail": tot[2] / n}
 
     def phase_a(self, only=None, kinds=None):
         """Coordinates of this rank's bands (optionally of one sub-grid / of some kinds of sub-grid only)."""

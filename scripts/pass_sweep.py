@@ -36,10 +36,17 @@ def timeit():
     for _ in range(args.steps):
         sg.run_pass()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / args.steps * 1e3
+    t = (time.perf_counter() - t0) / args.steps * 1e3
+    sg.pass_events = []
+    for _ in range(20):
+        sg.run_pass()
+    lt = sg.pass_launch_times_ms()
+    sg.pass_events = None
+    timeit.launches = "A %.1f B %.1f C %.1f us" % (lt["pass_a"] * 1e3, lt["pass_b"] * 1e3, lt["pass_tail"] * 1e3)
+    return t
 
 
-print("default: %.4f ms" % timeit())
+print("default: %.4f ms" % timeit(), timeit.launches)
 for mr, tw in itertools.product((1, 2, 4, 8), (2048, 4096, 8192, 16384)):
     os.environ["OGG_MESH_ROWS"], os.environ["OGG_QUAD_TARGET_WAVES"] = str(mr), str(tw)
     print("mesh rows/wg=%d quad target waves=%d: %.4f ms" % (mr, tw, timeit()), flush=True)
@@ -52,4 +59,4 @@ for wg, sp in itertools.product(wgs, args.split.split(",")):
         os.environ.pop("OGG_PASS_SPLIT", None)
     else:
         os.environ["OGG_PASS_SPLIT"] = sp
-    print("%s=%s split=%s: %.4f ms" % (key, wg, sp, timeit()), flush=True)
+    print("%s=%s split=%s: %.4f ms" % (key, wg, sp, timeit()), timeit.launches, flush=True)
