@@ -186,9 +186,10 @@ def main():
     if args.latlon == "fused" and args.launch == "auto":
         # set-up, untimed: every rank keeps the launch scheme that is fastest for ITS share (there is no collective in a pass)
         tuned = {}
-        cands = [("pass", 0, 0), ("pass", 0, 1), ("kernels", 1, 1), ("kernels", 0, 0)]
+        # (the pass is launched eagerly: a graph of its three launches gains nothing and would hide them from the events)
+        cands = [("pass", 0, 0), ("kernels", 1, 1), ("kernels", 0, 0)]
         if has_dp:  # the displaced-pole cap on a side stream next to the pass
-            cands += [("pass", 1, 0), ("pass", 1, 1)]
+            cands += [("pass", 1, 0)]
         for launch, overlap, graph in cands:
             sg.launch, sg.overlap = launch, bool(overlap)
             if graph and not can_graph:
@@ -208,21 +209,36 @@ def main():
         sg.launch, sg.overlap, use_graph = launch, overlap.endswith("1"), graph.endswith("1")
     elif args.latlon == "fused":
         sg.launch = args.launch
+        if args.launch == "pass":
+            use_graph = False
     for _ in range(args.warmup):
         sg.step()
     if use_graph:
         sg.capture()
         sg.replay()  # one untimed replay
     sync()
-    # timed region: exactly K passes
+    # timed region: exactly K passes.  In pass mode every `stride`-th pass also records HIP events around its three launches
+    # (on the launch stream, by the library itself): the per-launch durations of the roofline object come from the timed region.
+    sample = sg.launch == "pass" and not use_graph
+    stride = max(1, args.steps // 32)
+    if sample:
+        sg.reserve_pass_events(args.steps // stride + 1)
+        events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         if use_graph:
             sg.replay()
         else:
+            if sample:
+                sg.pass_events = events if k % stride == 0 else None
             sg.run_pass()
     sync()
     dt = time.perf_counter() - t0
+    launches = None
+    if sample:
+        sg.pass_events = events
+        launches = sg.pass_launch_times_ms()
+        sg.pass_events = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -252,12 +268,30 @@ def main():
             kernels[k] = {"launches_per_step": launches_per_step, "mean_ms": round(v["mean_ms"], 5),
                           "ms_per_step": round(v["total_ms"] / args.steps, 5), "alg_bytes_per_launch": int(alg_bytes),
                           "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            per_step = json.load(open(tfile)).get(args.workload, {}).get(dom)  # PMC bytes per step of that kernel
+        pmc = json.load(open(tfile)).get(args.workload, {}) if os.path.exists(tfile) else {}
+        if launches:  # the launches of the fused pass, timed inside the timed region
+            n_sampled = launches.pop("sampled_passes")
+            for k, v in launches.items():
+                gbs = v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
+                v.update({"ms": round(v["ms"], 5), "alg_bytes": int(v["alg_bytes"]), "alg_GBps": round(gbs, 1),
+                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+            dom = max(launches, key=lambda k: launches[k]["ms"])
+            roof = {"kernel": {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5>", "pass_tail": "bipolar_quad_tail_kernel<5>"}[dom],
+                    "bound": "hbm", "achieved": launches[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": launches[dom]["hbm_frac"], "traffic": pmc.get(dom),
+                    "note": "longest of the three launches of the fused pass; HIP events recorded by the library on the launch stream in "
+                            "%d passes of the timed region.  It carries lat-lon row strips (HBM-write bound) AND bipolar quadrature "
+                            "workgroups (fp64-VALU bound, DESIGN.md 4): its duration is set by the VALU work, its bytes mostly by the "
+                            "lat-lon strips.  `kernels` lists the stand-alone kernels, one after the other." % n_sampled}
+        else:
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            per_step = pmc.get(dom)  # PMC bytes per step of that kernel
             traffic = int(per_step / kernels[dom]["launches_per_step"]) if per_step else None
+            roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
+                    "note": "per-kernel durations from the sequential events pass; latlon_fused (78 % of the cells) is the HBM-bound "
+                            "kernel, the cap kernels are fp64-VALU bound (DESIGN.md 4)"}
         out = {
             "metric": "supergrid cells/sec (coords+metrics)", "value": plan.cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -269,10 +303,7 @@ def main():
             "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned,
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
-                         "note": "per-kernel durations from the sequential events pass; latlon_fused (78 % of the cells) is the HBM-bound "
-                                 "kernel, the cap kernels are fp64-VALU bound (DESIGN.md 4)"},
+            "roofline": roof, "pass_launches": launches,
             "kernels": kernels,
         }
         if world == 1 and args.cpu_sample_div > 0:

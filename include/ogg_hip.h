@@ -184,9 +184,10 @@ typedef struct ogg_bipolar_band {
 int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
                           int metrics, const ogg_bipolar_band* cap, void* stream);
 /* same; events4 (NULL, or 4 events from ogg_event_create) are recorded on the stream before the first launch and after each
- * of the three launches, so that the caller can time them (ogg_event_elapsed_ms) */
+ * of the three launches, so that the caller can time them (ogg_event_elapsed_ms); alg_bytes3 (NULL, or 3 doubles on the host)
+ * receives the bytes each launch writes (its share of the 48 B per cell) */
 int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
-                                 int metrics, const ogg_bipolar_band* cap, void** events4, void* stream);
+                                 int metrics, const ogg_bipolar_band* cap, void** events4, double* alg_bytes3, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Displaced-pole Southern cap

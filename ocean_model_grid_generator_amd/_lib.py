@@ -103,7 +103,7 @@ SIGNATURES = {
     "ogg_tripolar_pass_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
                               ctypes.POINTER(BipolarBand), c_void_p],
     "ogg_tripolar_pass_events_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
-                                     ctypes.POINTER(BipolarBand), ctypes.POINTER(c_void_p), c_void_p],
+                                     ctypes.POINTER(BipolarBand), ctypes.POINTER(c_void_p), ctypes.POINTER(c_double), c_void_p],
     "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],

@@ -5,13 +5,13 @@
 // on separate streams -- which costs 10-20 us of cross-queue signalling per dependency, as much as the kernels themselves
 // once the grid is split over 8 GPUs -- each launch carries workgroups of BOTH kinds, told apart by their workgroup index:
 //
-//   launch A:  lat-lon row strips [0, s1)  |  row/column tables of the quadrature  |  cap mesh + angle
-//   launch B:  lat-lon row strips [s1, S)  |  quadrature strips with the guard  |  quadrature strips without
+//   launch A:  row/column tables of the quadrature (a few microseconds)
+//   launch B:  lat-lon row strips  |  cap mesh + angle  |  quadrature strips with the guard  |  quadrature strips without
 //   launch C:  literal fix-up of the cells the guard handed over  |  j = ny row of the quadrature (literal)
+// (without metrics there is no quadrature: launch A then carries the lat-lon strips and the mesh, and B, C do not exist)
 //
 // The lat-lon workgroups come first in the index space (they are resident from the start and walk their strips grid-stride
-// while the compute workgroups stream through the remaining slots); s1 splits the lat-lon strips in proportion to the
-// estimated VALU time of launches A and B.  Every workgroup runs the same body function as the stand-alone kernels of
+// while the compute workgroups stream through the remaining slots).  Every workgroup runs the same body function as the stand-alone kernels of
 // ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level entry points.
 #include "ogg_bipolar_dev.h"
 #include "ogg_latlon_fused_dev.h"
@@ -61,6 +61,8 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
 struct PassBParams {
     FusedParams ll;
     LatlonShare share;
+    MeshParams mesh;        // layout "tb": the cap mesh runs here, next to the quadrature, and launch A only builds the tables
+    long mesh_gx, n_mesh;
     QuadParams q;
     QuadRange guard, fast;
     long gx, n_guard, n_fast;
@@ -68,13 +70,18 @@ struct PassBParams {
 
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
-    __shared__ RowScalars lds[LF_ROWS + 1];
+    __shared__ PassLds lds;
     long b = blockIdx.x;
     if (b < a.share.n_wg) {
-        latlon_fused_body(a.ll, lds, b % a.share.gx, b / a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        latlon_fused_body(a.ll, lds.ll, b % a.share.gx, b / a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
         return;
     }
     b -= a.share.n_wg;
+    if (b < a.n_mesh) {
+        bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
+        return;
+    }
+    b -= a.n_mesh;
     if (b < a.n_guard) {
         bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
         return;
@@ -96,7 +103,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // resident lat-lon workgroups: enough to keep the HBM write path busy and not more, so that the VALU-bound workgroups of
     // the same launch get the remaining wave slots; a launch without compute workgroups takes the whole chip
     const long points = (hi - lo) * ll.rows_per_block * ni1;
-    long max_wg = alone ? 2048 : (points >= 4000000 ? env_long("OGG_PASS_LL_WG", 84) : env_long("OGG_PASS_LL_WG_SMALL", 120));
+    long max_wg = alone ? 2048 : (points >= 4000000 ? env_long("OGG_PASS_LL_WG", 60) : env_long("OGG_PASS_LL_WG_SMALL", 120));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
     s.gy = gy < 1 ? 1 : gy;
@@ -104,8 +111,27 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     return s;
 }
 
+// bytes the lat-lon row strips [lo, hi) write: x, y, angle_dx (ni1 per row), dx (ni), and dy (ni1), area (ni) on cell rows
+double latlon_strip_bytes(const FusedParams& ll, long lo, long hi) {
+    const long ni1 = ll.ni1, ni = ni1 - 1;
+    double bytes = 0.0;
+    for (int k = 0; k < ll.n_bands; ++k) {
+        const long s0 = ll.strip0[k] > lo ? ll.strip0[k] : lo, s1 = ll.strip0[k + 1] < hi ? ll.strip0[k + 1] : hi;
+        if (s1 <= s0) continue;
+        const ogg_latlon_band& b = ll.band[k];
+        const long r0 = (s0 - ll.strip0[k]) * ll.rows_per_block;
+        long r1 = (s1 - ll.strip0[k]) * ll.rows_per_block;
+        if (r1 > b.n_pt_rows) r1 = b.n_pt_rows;
+        const long ncell = ll.metrics ? b.n_cell_rows : 0;
+        const long c1 = r1 < ncell ? r1 : ncell, c0 = r0 < ncell ? r0 : ncell;
+        bytes += 8.0 * ((double)(r1 - r0) * (3 * ni1 + (ll.metrics ? ni : 0)) + (double)(c1 - c0) * (ni1 + ni));
+    }
+    return bytes;
+}
+
 template <int N>
-int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, hipEvent_t* ev, hipStream_t st) {
+int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, hipEvent_t* ev, double* alg_bytes3,
+                hipStream_t st) {
     // ev: NULL, or 4 events recorded before launch A and after launches A, B and C (bench.py times the launches with them)
     auto mark = [&](int k) -> int {
         if (ev) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
@@ -140,7 +166,16 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     // 1/8 degree: mesh 1, plain quadrature 2.1, guarded quadrature 3.1)
     long s1 = n_strips_ll;
     const bool launch_b = have_quad && (B.n_guard + B.n_fast > 0);
-    if (launch_b) {
+    // Default layout: launch A builds only the tables and launch B carries everything else, the cap mesh included -- one
+    // long launch in which all three kinds of workgroup overlap (measured faster than mesh + part of the lat-lon strips in A
+    // at every share from 1 to 1/8 of the 1/8 degree grid).  OGG_PASS_LAYOUT=ab selects that older split.
+    const char* lay = getenv("OGG_PASS_LAYOUT");
+    const bool layout_tb = launch_b && !(lay && lay[0] == 'a');
+    if (layout_tb) {
+        B.mesh = A.mesh, B.mesh_gx = A.mesh_gx, B.n_mesh = A.n_mesh;
+        A.n_mesh = 0;
+        s1 = 0;
+    } else if (launch_b) {
         const double ta = have_cap ? (double)cap->n_pt_rows : 0.0;
         const double tb = (qp.has_fast ? 2.1 * (double)(qp.fast.row_end - qp.fast.row_begin) : 0.0) +
                           (qp.has_guard ? 3.1 * (double)(qp.guard.row_end - qp.guard.row_begin) : 0.0);
@@ -148,6 +183,12 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         if (const char* e = getenv("OGG_PASS_SPLIT")) f = atof(e);
         s1 = (long)llround(f * (double)n_strips_ll);
         s1 = s1 < 0 ? 0 : (s1 > n_strips_ll ? n_strips_ll : s1);
+    }
+    if (alg_bytes3) {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
+        const double ni = (double)(ni1 - 1);
+        alg_bytes3[0] = latlon_strip_bytes(ll, 0, s1) + (have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0);
+        alg_bytes3[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) : 0.0;
+        alg_bytes3[2] = (have_quad && qp.has_top) ? 8.0 * ni : 0.0;
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap);
     const long na = A.share.n_wg + A.n_tab + A.n_mesh;
@@ -159,7 +200,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     if (int e = mark(1)) return e;
     if (launch_b) {
         B.share = make_share(ll, s1, n_strips_ll, ni1, false);
-        const unsigned nb = (unsigned)(B.share.n_wg + B.n_guard + B.n_fast);
+        const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_guard + B.n_fast);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
         OGG_LAUNCH_CHECK();
     }
@@ -173,7 +214,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
 }  // namespace
 
 extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
-                                            int metrics, const ogg_bipolar_band* cap, void** events4, void* stream) {
+                                            int metrics, const ogg_bipolar_band* cap, void** events4, double* alg_bytes3, void* stream) {
     FusedParams ll;
     long points = 0;
     if (int e = plan_latlon(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, ll, points)) return e;
@@ -198,14 +239,14 @@ extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band*
     hipStream_t st = ogg::as_stream(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(events4);
     switch (order) {
-        case 2: return launch_pass<2>(ll, ni1, metrics, cap, ev, st);
-        case 3: return launch_pass<3>(ll, ni1, metrics, cap, ev, st);
-        case 4: return launch_pass<4>(ll, ni1, metrics, cap, ev, st);
-        default: return launch_pass<5>(ll, ni1, metrics, cap, ev, st);
+        case 2: return launch_pass<2>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
+        case 3: return launch_pass<3>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
+        case 4: return launch_pass<4>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
+        default: return launch_pass<5>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
     }
 }
 
 extern "C" int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
                                      int metrics, const ogg_bipolar_band* cap, void* stream) {
-    return ogg_tripolar_pass_events_dev(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, nullptr, stream);
+    return ogg_tripolar_pass_events_dev(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, nullptr, nullptr, stream);
 }

@@ -189,6 +189,8 @@ class Supergrid(object):
         # of work sharing each launch); "kernels": one call per sub-grid and phase, on side streams when `overlap` is set
         self.launch = "kernels"
         self.pass_events = None  # a list: tripolar_pass() times its launches into it
+        self._event_pool = []
+        self._pass_args = None
         self._side = None
         self.buf = {}
         self.timings = {}
@@ -278,37 +280,53 @@ class Supergrid(object):
     def tripolar_pass(self):
         """Lat-lon sub-grids and the bipolar cap of this rank through ogg_tripolar_pass_dev."""
         p, st = self.plan, self._stream()
-        bands = self._latlon_bands()
-        arr = (L.LatlonBand * max(len(bands), 1))(*bands)
-        cap = None
-        for s in p.subs:
-            b = self.buf[s.name]
-            if s.kind == "bipolar" and b["n"] > 0:
-                cap = L.BipolarBand()
-                cap.Ni, cap.Nj, cap.lat0_bp, cap.lon_bp, cap.rp, cap.Re, cap.order = p.Ni, s.Nj, s.lat0_bp, s.lon_bp, s.rp, p.Re, 5
-                cap.j0, cap.n_pt_rows, cap.n_cell_rows = b["lo"], b["n"], b["n_cell"]
-                cap.x, cap.y, cap.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
-                cap.dx = b["dx"].data_ptr()
-                cap.dy = b["dy"].data_ptr() if b["n_cell"] else None
-                cap.area = b["area"].data_ptr() if b["n_cell"] else None
-                cap.workspace, cap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
+        if self._pass_args is None:  # the descriptors only hold scalars and buffer addresses, which never change: build once
+            bands = self._latlon_bands()
+            arr = (L.LatlonBand * max(len(bands), 1))(*bands)
+            cap = None
+            for s in p.subs:
+                b = self.buf[s.name]
+                if s.kind == "bipolar" and b["n"] > 0:
+                    cap = L.BipolarBand()
+                    cap.Ni, cap.Nj, cap.lat0_bp, cap.lon_bp, cap.rp, cap.Re, cap.order = p.Ni, s.Nj, s.lat0_bp, s.lon_bp, s.rp, p.Re, 5
+                    cap.j0, cap.n_pt_rows, cap.n_cell_rows = b["lo"], b["n"], b["n_cell"]
+                    cap.x, cap.y, cap.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
+                    cap.dx = b["dx"].data_ptr()
+                    cap.dy = b["dy"].data_ptr() if b["n_cell"] else None
+                    cap.area = b["area"].data_ptr() if b["n_cell"] else None
+                    cap.workspace, cap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
+            self._pass_args = (bands, arr, cap)
+        bands, arr, cap = self._pass_args
         capref = ctypes.byref(cap) if cap is not None else None
         if self.pass_events is None:
             L.call("ogg_tripolar_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, st)
             return
         # per-launch timing: four HIP events recorded by the library around its three launches
+        evs = self._event_pool.pop() if self._event_pool else self._new_events()
+        self.pass_bytes = (ctypes.c_double * 3)()
+        L.call("ogg_tripolar_pass_events_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, evs,
+               self.pass_bytes, st)
+        self.pass_events.append(evs)
+
+    @staticmethod
+    def _new_events():
         evs = (ctypes.c_void_p * 4)()
         for k in range(4):
             e = ctypes.c_void_p()
             L.call("ogg_event_create", ctypes.byref(e))
             evs[k] = e
-        L.call("ogg_tripolar_pass_events_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, evs, st)
-        self.pass_events.append(evs)
+        return evs
+
+    def reserve_pass_events(self, n):
+        """Create the events for n timed passes ahead of a timed region."""
+        self._event_pool = [self._new_events() for _ in range(n)]
 
     def pass_launch_times_ms(self):
-        """Mean duration of the three launches of the fused pass over the passes run since `pass_events = []`."""
+        """Mean duration and algorithmic bytes of the three launches of the fused pass over the passes that ran while
+        `pass_events` was a list; empties the list."""
         L.call("ogg_stream_synchronize", self._stream())
         tot = [0.0, 0.0, 0.0]
+        n = len(self.pass_events)
         for evs in self.pass_events:
             for k in range(3):
                 ms = ctypes.c_float()
@@ -316,9 +334,11 @@ class Supergrid(object):
                 tot[k] += ms.value
             for k in range(4):
                 L.call("ogg_event_destroy", evs[k])
-        n = max(len(self.pass_events), 1)
         self.pass_events = []
-        return {"pass_a": tot[0] / n, "pass_b": tot[1] / n, "pass_tail": tot[2] / n}
+        by = list(self.pass_bytes) if n else [0.0, 0.0, 0.0]
+        out = {name: {"ms": tot[k] / max(n, 1), "alg_bytes": by[k]} for k, name in enumerate(("pass_a", "pass_b", "pass_tail"))}
+        out["sampled_passes"] = n
+        return out
 
     def phase_a(self, only=None, kinds=None):
         """Coordinates of this rank's bands (optionally of one sub-grid / of some kinds of sub-grid only)."""

@@ -42,15 +42,15 @@ def timeit():
         sg.run_pass()
     lt = sg.pass_launch_times_ms()
     sg.pass_events = None
-    timeit.launches = "A %.1f B %.1f C %.1f us" % (lt["pass_a"] * 1e3, lt["pass_b"] * 1e3, lt["pass_tail"] * 1e3)
+    timeit.launches = "A %.1f B %.1f C %.1f us" % (lt["pass_a"]["ms"] * 1e3, lt["pass_b"]["ms"] * 1e3, lt["pass_tail"]["ms"] * 1e3)
     return t
 
 
 print("default: %.4f ms" % timeit(), timeit.launches)
-for mr, tw in itertools.product((1, 2, 4, 8), (2048, 4096, 8192, 16384)):
-    os.environ["OGG_MESH_ROWS"], os.environ["OGG_QUAD_TARGET_WAVES"] = str(mr), str(tw)
-    print("mesh rows/wg=%d quad target waves=%d: %.4f ms" % (mr, tw, timeit()), flush=True)
-os.environ.pop("OGG_MESH_ROWS"), os.environ.pop("OGG_QUAD_TARGET_WAVES")
+for lay in ("ab", "tb", "ab", "tb"):
+    os.environ["OGG_PASS_LAYOUT"] = lay
+    print("layout %s: %.4f ms" % (lay, timeit()), timeit.launches, flush=True)
+os.environ.pop("OGG_PASS_LAYOUT")
 key = "OGG_PASS_LL_WG_SMALL" if args.wg_small else "OGG_PASS_LL_WG"
 wgs = (args.wg_small or args.wg).split(",")
 for wg, sp in itertools.product(wgs, args.split.split(",")):
