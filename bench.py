@@ -179,6 +179,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # set-up, untimed: 60 passes so that the clocks have ramped before anything is compared or timed
+    if args.latlon == "fused":
+        sg.launch = "pass"
+    for _ in range(60):  # a fixed count: in the stencil pipeline every pass holds a neighbour exchange
+        sg.run_pass()
+    torch.cuda.synchronize()
+    sg.launch = "kernels"
     can_graph = not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
     use_graph = bool(args.graph) and can_graph
     tuned = None

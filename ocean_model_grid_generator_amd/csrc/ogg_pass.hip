@@ -186,8 +186,11 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     }
     if (alg_bytes3) {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
         const double ni = (double)(ni1 - 1);
-        alg_bytes3[0] = latlon_strip_bytes(ll, 0, s1) + (have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0);
-        alg_bytes3[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) : 0.0;
+        const double mesh_bytes = have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0;
+        alg_bytes3[0] = latlon_strip_bytes(ll, 0, s1) + (layout_tb ? 0.0 : mesh_bytes);
+        alg_bytes3[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) +
+                                       (layout_tb ? mesh_bytes : 0.0)
+                                 : 0.0;
         alg_bytes3[2] = (have_quad && qp.has_top) ? 8.0 * ni : 0.0;
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap);
