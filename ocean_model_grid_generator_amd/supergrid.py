@@ -187,7 +187,7 @@ class Supergrid(object):
         self.overlap = True
         # "pass": lat-lon sub-grids + bipolar cap through ogg_tripolar_pass_dev (three launches on one stream, the two kinds
         # of work sharing each launch); "kernels": one call per sub-grid and phase, on side streams when `overlap` is set
-        self.launch = "kernels"
+        self.launch = "pass" if latlon == "fused" else "kernels"
         self.pass_events = None  # a list: tripolar_pass() times its launches into it
         self._event_pool = []
         self._pass_args = None

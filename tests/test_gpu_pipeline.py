@@ -104,6 +104,76 @@ def test_tripolar_pass_is_bit_identical_to_separate_kernels(sg, name, world):
         assert np.array_equal(kernels[f], fused[f], equal_nan=False), (f, world)
 
 
+def test_tripolar_pass_full_size_r8_bitwise(sg):
+    """1/8 degree, the benchmark workload: the fused pass against one launch per sub-grid and phase, compared on the device."""
+    import torch
+    plan = sg.SupergridPlan(8.0)
+    for world, rank in ((1, 0), (8, 7), (8, 2)):
+        a = sg.Supergrid(plan, rank=rank, world=world, device="cuda:0", halo="recompute", latlon="fused")
+        b = sg.Supergrid(plan, rank=rank, world=world, device="cuda:0", halo="recompute", latlon="fused")
+        a.launch, b.launch, b.overlap = "pass", "kernels", False
+        for s in plan.subs:
+            for f in FIELDS:
+                a.buf[s.name][f].fill_(float("nan"))
+        a.step()
+        b.step()
+        torch.cuda.synchronize()
+        for s in plan.subs:
+            for f in FIELDS:
+                assert torch.equal(a.buf[s.name][f], b.buf[s.name][f]), (world, rank, s.name, f)
+        del a, b
+
+
+def test_tripolar_pass_argument_errors(sg):
+    import ctypes
+    import torch
+    from ocean_model_grid_generator_amd import _lib as L
+    plan = sg.SupergridPlan(1.0)
+    g = sg.Supergrid(plan, device="cuda:0")
+    g.step()
+    bands, arr, cap = g._pass_args
+    st = torch.cuda.current_stream().cuda_stream
+    bad = L.BipolarBand.from_buffer_copy(cap)
+    bad.order = 7
+    with pytest.raises(Exception, match="Uncoded order"):       # the reference's own exception and text (OGG:204)
+        L.call("ogg_tripolar_pass_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(bad), st)
+    bad = L.BipolarBand.from_buffer_copy(cap)
+    bad.workspace = None
+    with pytest.raises(L.OggHipError, match="workspace"):
+        L.call("ogg_tripolar_pass_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(bad), st)
+    bad = L.BipolarBand.from_buffer_copy(cap)
+    bad.Ni = plan.Ni + 2
+    with pytest.raises(Exception, match="columns"):
+        L.call("ogg_tripolar_pass_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(bad), st)
+    # no cap at all (a rank without cap rows) and no lat-lon band at all are both fine
+    L.call("ogg_tripolar_pass_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, None, st)
+    L.call("ogg_tripolar_pass_dev", 0, arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(cap), st)
+    torch.cuda.synchronize()
+
+
+def test_bench_json_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and the CPU baseline (smallest workload)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "r2", "--steps", "4", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["unit"] == "cells/s" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["cells"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cells/s" and c["sample"]
+
+
 def test_more_ranks_than_rows(sg):
     """Tiny sub-grids: some ranks own no rows of a sub-grid, the top band may own only the fold row."""
     plan = sg.SupergridPlan(0.25, ensure_nj_even=True)
