@@ -69,9 +69,9 @@ int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0
                     (n_dx_rows == n_cell_rows || (n_dx_rows == n_cell_rows + 1 && j0 + n_cell_rows == ny)),
                 OGG_ESHAPE, "ogg_bipolar_cap_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0, n_cell_rows,
                 n_dx_rows, ny);
-    // OGG_BP_GUARD_K: threshold of the exactness guard (see bp_point_fast).  Default 1000; 0 hands every cell to the
+    // OGG_BP_GUARD_K: threshold of the exactness guard (see bp_point_fast).  Default 4000; 0 hands every cell to the
     // literal fix-up (slow; used by the tests to compare the two paths).
-    double gap = 1000.0;
+    double gap = BP_GUARD_K_DEFAULT;
     if (const char* e = getenv("OGG_BP_GUARD_K")) gap = atof(e);
     QuadParams p{};
     p.nx = nx, p.ny = ny, p.lat0_bp = lat0_bp, p.lon_bp = lon_bp, p.rp = rp, p.Re = Re, p.j0 = j0;

@@ -115,7 +115,10 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
     // its cosine, which perturbs cos^2(phis) by up to 2.4e-16 / atan(rp t) relative; the algebraic value does not have that
     // perturbation, so where the cos^2 term carries weight w in h^2 the two differ by ~ w * 1.2e-16 / atan(rp t) in h.
     // With atan(u) >= u/(1+u^2) = sqrt(cc)/2 the point is handed to the literal fix-up when w^2 > K * cc, i.e. when the
-    // difference could exceed ~ 2.4e-16 / sqrt(K) * ... (K = 1000: measured worst unflagged difference 8e-15 at 1/8 degree).
+    // difference could exceed ~ 2.4e-16 / sqrt(K) * ...  Measured against the oracle on the top 100 cell rows of the 1/8 degree cap
+    // (scripts/guard_k_probe.py), worst relative difference of dx / dy / area: every cell literal 5.8e-15 / 4.3e-15 / 3.5e-15
+    // (ocml vs the host libm), K = 1000 5.8 / 6.1 / 5.0e-15, K = 4000 (default) 8.4 / 7.7 / 8.9e-15 with a quarter of the fix-up
+    // cells, K = 16000 1.5e-14, no guard at all 6.8e-14 / 1.4e-13 / 6.9e-14 (area still within 3.3e-7 m^2).
     // Since w <= 1 a point can only be guarded where cos^2(phis) < 1/K, i.e. (phis <= grid latitude of the row) on the
     // lattice rows with cos^2(lat) < 1/K: the rows below that latitude run the GUARD = false instantiation.
     if (!GUARD) return false;
@@ -256,6 +259,8 @@ inline dim3 mesh_grid(MeshParams& m) {
     m.rows_per_wg = (int)rpw;
     return dim3((unsigned)gx, (unsigned)((m.nrows + rpw - 1) / rpw));
 }
+
+constexpr double BP_GUARD_K_DEFAULT = 4000.0;  // exactness guard of bp_point_fast; OGG_BP_GUARD_K overrides
 
 // ---- quadrature metrics -------------------------------------------------------------------------------------
 struct QuadParams {

@@ -150,7 +150,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         A.mesh_gx = mg.x, A.n_mesh = (long)mg.x * mg.y;
     }
     if (have_quad) {
-        double guard_k = 1000.0;
+        double guard_k = BP_GUARD_K_DEFAULT;
         if (const char* e = getenv("OGG_BP_GUARD_K")) guard_k = atof(e);
         QuadParams p{};
         p.nx = cap->Ni, p.ny = cap->Nj, p.lat0_bp = cap->lat0_bp, p.lon_bp = cap->lon_bp, p.rp = cap->rp, p.Re = cap->Re, p.j0 = cap->j0;

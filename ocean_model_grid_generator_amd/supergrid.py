@@ -110,7 +110,7 @@ class SupergridPlan(object):
         # that equalise the measured per-rank times of the fused pass at 1/8 degree over 2, 4 and 8 ranks
         # (scripts/rank_sweep.py; OGG_BP_ROW_COST="fix,guard" overrides them).
         import os
-        K = float(os.environ.get("OGG_BP_GUARD_K", "1000"))
+        K = float(os.environ.get("OGG_BP_GUARD_K", "4000"))
         if K > 4.0:
             lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
             guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
