@@ -90,10 +90,15 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
 // LITERAL sequence loses digits (phis = 90 - small is rounded to 1 ulp of 90 before the cosine), and parity with the
 // reference means reproducing that: every point carries a guard (below) and the cells with a guarded point are
 // re-evaluated with bp_point by a fix-up kernel (about 0.4 % of the cells at 1/8 degree, around the two pole points).
+//
+// Factored once more for the instruction count: with rden = 1/P, E = 1/D, Qs = E^2 rden, S = (1-A)(1+A) rden,
+//   h_j^2 N^2 = 4 rp^2 Qs X,  X = S a(1-a) b(1+b) + (1-a)          (OGG:81-88)
+//   h_i^2     = 4 rp^2 Qs Y,  Y = S (1+b) + a b                    (OGG:89-95)
+// and the callers fold 4 rp^2 into their per-row scale factors.
 template <bool GUARD>
-OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
-                           double guard_k, double& hi2, double& hj2) {
-    // bb1 = b (1+b) is row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them
+OGG_DEV bool bp_point_fast(const BpRow& r, double b1, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
+                           double guard_k, double& Qs, double& X, double& Y) {
+    // b1 = 1+b and bb1 = b (1+b) are row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them
     const double a = c.alpha2, b = r.beta2_inv;
     const double ab = a * b;
     const double A = c.sinla * r.sphig;
@@ -102,13 +107,13 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
     const double D = fma(rp2, m1, p1);
     const double inv = rcp_nr(P * D);             // one reciprocal for both quotients
     const double rden = D * inv, E = P * inv;
-    const double MM = rp2x4 * (E * E);            // M_inv^2
-    const double cc = MM * (m1 * p1);             // cos^2(phis) = sin^2(2 atan(rp t))
-    const double ccrr = cc * (rden * rden);
-    const double Mr = MM * rden;
-    const double t1j = ccrr * (aa1 * bb1), t1i = ccrr * (1 + b);
-    hj2 = fma(Mr, a1, t1j);
-    hi2 = fma(Mr, ab, t1i);
+    const double EE = E * E;
+    const double mp = m1 * p1;
+    const double S = mp * rden;
+    const double uj = S * (aa1 * bb1), ui = S * b1;   // the cos^2(phis) terms of h_j^2, h_i^2 (up to the common factor)
+    Qs = EE * rden;
+    X = uj + a1;
+    Y = ui + ab;
     // (the |beta2_inv| > HUGE case of OGG:86,94 only occurs on the exact j = ny row, which never takes this path)
     //
     // Exactness guard.  The literal sequence rounds phis = 90 - 2 atan(rp t)/PI_180 to a multiple of ulp(90) before taking
@@ -122,9 +127,8 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double bb1, const BpCol& c, double a1
     // Since w <= 1 a point can only be guarded where cos^2(phis) < 1/K, i.e. (phis <= grid latitude of the row) on the
     // lattice rows with cos^2(lat) < 1/K: the rows below that latitude run the GUARD = false instantiation.
     if (!GUARD) return false;
-    const double gi = t1i * t1i, gj = t1j * t1j;
-    const double kc = guard_k * cc;
-    return (gi > kc * (hi2 * hi2)) || (gj > kc * (hj2 * hj2));
+    const double kc = guard_k * (rp2x4 * (EE * mp));   // K cos^2(phis)
+    return (ui * ui > kc * (Y * Y)) || (uj * uj > kc * (X * X));
 }
 
 // lams of OGG:50-64
@@ -389,24 +393,26 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
             if (ii == 0) o.dy0 = dy;
         }
     } else {
-        const double bb1 = r.beta2_inv * (1 + r.beta2_inv), nsy = r.N_inv * sy;
+        const double b1 = 1 + r.beta2_inv, bb1 = r.beta2_inv * b1, nsy = r.N_inv * sy;
+        // 4 rp^2 folded into the scale factors of OGG:131-132: sqrt(4 rp^2) = 2 rp
+        const double cdx = (2 * p.rp) * sx, cdy = (2 * p.rp) * nsy, cpr = rp2x4 * (sx * nsy);
         int g_first = 0, g_any = 0;
 #pragma unroll
         for (int ii = 0; ii < M; ++ii) {
-            double hi2, hj2;
+            double Qs, X, Y;
             const double a1 = 1 - col[ii].alpha2;
-            const bool g = bp_point_fast<MODE == QM_GUARD>(r, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, p.guard_k, hi2, hj2);
+            const bool g = bp_point_fast<MODE == QM_GUARD>(r, b1, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, p.guard_k, Qs, X, Y);
             if (ii == 0) g_first = g;
             g_any |= (int)g;
             // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): sqrt_nr(0) would be 0 * inf
             if (ii == 0 || want_dx) {
-                const double dx = sqrt_nr(hi2) * sx;
-                const double dy = (hj2 > 0.0) ? sqrt_nr(hj2) * nsy : 0.0;
+                const double dx = sqrt_nr(Qs * Y) * cdx;
+                const double dy = (X > 0.0) ? sqrt_nr(Qs * X) * cdy : 0.0;
                 o.dx[ii] = dx;
                 o.pr[ii] = dx * dy;
                 if (ii == 0) o.dy0 = dy;
             } else {
-                o.pr[ii] = (hj2 > 0.0) ? sqrt_nr(hi2 * hj2) * (sx * nsy) : 0.0;
+                o.pr[ii] = (X > 0.0) ? (sqrt_nr(X * Y) * Qs) * cpr : 0.0;
             }
         }
         o.guarded = 0;
