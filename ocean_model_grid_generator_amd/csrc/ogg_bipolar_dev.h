@@ -230,8 +230,8 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
             if (out && hj && j < Nj) hj[jl * ni1 + i] = h_j * kPi180 * (90 - lat0_bp) / (double)Nj;   // OGG:120
         }
         if (angle) {                                                                   // OGG:725-728
-            const double xl = __shfl_up(lam, 1), xr = __shfl_down(lam, 1);
-            const double yl = __shfl_up(phi, 1), yr = __shfl_down(phi, 1);
+            const double xl = wave_prev(lam), xr = wave_next(lam);
+            const double yl = wave_prev(phi), yr = wave_next(phi);
             // cos(phi PI/180) = sin(2 atan u) = 2u/(1+u^2): differs from the cosine of the ROUNDED phi by < 7e-15/(90-phi) relative,
             // three orders below what the last-ulp differences of lam, phi do to their finite differences here
             const double cy = (2 * u) / (1 + u * u);
@@ -416,11 +416,11 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
             }
         }
         o.guarded = 0;
-        if (MODE == QM_GUARD) o.guarded = g_any | __shfl_down(g_first, 1);  // the right edge is lane+1's first column
+        if (MODE == QM_GUARD) o.guarded = g_any | wave_next(g_first);  // the right edge is lane+1's first column
     }
     if (FAITHFUL) o.guarded = 0;
-    if (FAITHFUL || want_dx) o.dx[M] = __shfl_down(o.dx[0], 1);
-    o.pr[M] = __shfl_down(o.pr[0], 1);
+    if (FAITHFUL || want_dx) o.dx[M] = wave_next(o.dx[0]);
+    o.pr[M] = wave_next(o.pr[0]);
 }
 
 template <int N, int MODE>

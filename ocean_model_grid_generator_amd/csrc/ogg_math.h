@@ -122,6 +122,23 @@ OGG_DEV double sqrt_nr(double x) {
     return fma(d, h, g);
 }
 
+// Neighbour lanes of a wave64 through DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130): two VALU moves per
+// double instead of two ds_bpermute round trips through the LDS crossbar.  The end lanes keep their own value, like
+// __shfl_up / __shfl_down with delta 1.
+OGG_DEV double wave_prev(double x) {  // lane l gets the value of lane l-1
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+OGG_DEV double wave_next(double x) {  // lane l gets the value of lane l+1
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+OGG_DEV int wave_next(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
+
 // Gauss-Lobatto node weights of OGG:191-204, computed on the host in IEEE double and passed by value.
 struct QuadNodes {
     double a[5];

@@ -42,10 +42,10 @@ OGG_DEV RowVals load_row(const double* __restrict__ x, const double* __restrict_
     const double* yrow = y + row * ni1;
     v.xc = xrow[ic];
     v.yc = yrow[ic];
-    v.xr = __shfl_down(v.xc, 1);
-    v.yr = __shfl_down(v.yc, 1);
-    v.xl = __shfl_up(v.xc, 1);
-    v.yl = __shfl_up(v.yc, 1);
+    v.xr = wave_next(v.xc);
+    v.yr = wave_next(v.yc);
+    v.xl = wave_prev(v.xc);
+    v.yl = wave_prev(v.yc);
     if (lane == 63) {
         const long ir = (ic + 1 < ni1) ? ic + 1 : ni1 - 1;
         v.xr = xrow[ir];
