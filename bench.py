@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--as-world", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="run the caps on side streams next to the lat-lon sub-grids")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
+    ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
                     help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
                          "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
@@ -250,6 +251,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # self-check, untimed: the reference's CHECK_metrics numbers (OGG:732-770) for the bands now in HBM -- five sums per band on the
+    # device and one all-reduce (RCCL) of n_subs x 7 doubles, the only collective of the default pipeline
+    self_check = None
+    if not plan.skip_metrics and args.self_check:
+        try:
+            if args.as_rank is None:
+                self_check = {k: [float(e) for e in v] for k, v in sg.metrics_error().items()}
+        except Exception as exc:  # never lose the bench line over the self-check
+            self_check = {"error": repr(exc)}
     # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
     # stream (events cannot be read back from inside a replayed graph)
     timed_launch = "%s%s%s" % (sg.launch, ", caps on side streams" if (sg.launch == "kernels" and sg.overlap) else (", displaced-pole cap on a side stream" if (sg.overlap and has_dp) else ""),
@@ -311,6 +321,7 @@ def main():
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": roof, "pass_launches": launches,
+            "self_check_metrics_error_percent": self_check,
             "kernels": kernels,
         }
         if world == 1 and args.cpu_sample_div > 0:

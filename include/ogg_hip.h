@@ -246,6 +246,12 @@ int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, do
  * Device utilities used by the band-sharded pipeline (bench / multi-GPU)
  * ---------------------------------------------------------------------------------------------------- */
 int ogg_fill_dev(long n, double value, double* out, void* stream);
+/* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:
+ * out5 = { sum(area), sum(dy[:, col_a]), sum(dy[:, col_b]) (0 when col_b < 0), sum(dx[0, :]) if want_first_row,
+ * sum(dx[n_dx_rows-1, :]) if want_last_row }.  dx: n_dx_rows x ni, dy: n_cell_rows x (ni+1), area: n_cell_rows x ni; out5 is a
+ * device pointer.  A band-sharded run adds the out5 of all ranks (one all-reduce) and evaluates OGG:735-770 on the host. */
+int ogg_metrics_sums_dev(long n_dx_rows, long n_cell_rows, long ni, const double* dx, const double* dy, const double* area,
+                         long col_a, long col_b, int want_first_row, int want_last_row, double* out5, void* stream);
 /* per-launch timing of the dominant kernels with HIP events on the given stream: start/stop bracket */
 int ogg_event_create(void** ev);
 int ogg_event_destroy(void* ev);

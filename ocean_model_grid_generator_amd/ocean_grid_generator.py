@@ -498,32 +498,49 @@ def angle_x(x, y):
     return out
 
 
-def metrics_error(dx_, dy_, area_, Ni, lat1, lat2=90, Re=_default_Re, bipolar=False, displaced_pole=-999,
-                  excluded_fraction=None):
-    """Self-check of OGG:732-770: a few host reductions over device-produced fields, compared with the sphere."""
+def metrics_error_from_sums(area_sum, dy_col_a, dy_col_b, dx_first_row, dx_last_row, lat1, lat2=90, Re=_default_Re, bipolar=False,
+                            displaced_pole=-999, excluded_fraction=None):
+    """OGG:735-770 given the five sums it takes over the fields: sum(area), sum(dy[:, Ni//4]) (or, for a displaced pole,
+    sum(dy[:, pole]) and sum(dy[:, antipole])), sum(dx[0, :]), sum(dx[-1, :]).  ``metrics_error`` forms them on the host from
+    arrays; ``supergrid.Supergrid.metrics_error`` forms them on the device per band and adds them over the ranks."""
     exact_area = 2 * np.pi * (Re ** 2) * np.abs(np.sin(lat2 * PI_180) - np.sin(lat1 * PI_180))
     exact_lat_arc_length = np.abs(lat2 - lat1) * PI_180 * Re
     exact_lon_arc_length = np.cos(lat1 * PI_180) * 2 * np.pi * Re
-    grid_lat_arc_length = np.sum(dy_[:, Ni // 4])
-    grid_lon_arc_length = np.sum(dx_[0, :])
+    grid_lat_arc_length = dy_col_a
+    grid_lon_arc_length = dx_first_row
     if lat1 > lat2:
-        grid_lon_arc_length = np.sum(dx_[-1, :])
+        grid_lon_arc_length = dx_last_row
     if bipolar:
-        lon_arc2_error = 100 * (np.sum(dx_[-1, :]) / 4 - exact_lat_arc_length) / exact_lat_arc_length
-    area_error = 100 * (np.sum(area_) - exact_area) / exact_area
+        lon_arc2_error = 100 * (dx_last_row / 4 - exact_lat_arc_length) / exact_lat_arc_length
+    area_error = 100 * (area_sum - exact_area) / exact_area
     lat_arc_error = 100 * (grid_lat_arc_length - exact_lat_arc_length) / exact_lat_arc_length
     lon_arc_error = 100 * (grid_lon_arc_length - exact_lon_arc_length) / exact_lon_arc_length
     if displaced_pole != -999:
-        antipole = displaced_pole + Ni // 2
-        if displaced_pole > Ni // 2:
-            antipole = displaced_pole - Ni // 2
-        grid_lat_arc_length = np.sum(dy_[:, displaced_pole]) + np.sum(dy_[:, antipole])
+        grid_lat_arc_length = dy_col_a + dy_col_b
         lat_arc_error = 100 * (grid_lat_arc_length - 2.0 * exact_lat_arc_length) / exact_lat_arc_length
     if excluded_fraction:
         print("   Cannot estimate area and dy accuracies with excluded_fraction (doughnut)! ")
     if bipolar:
         return area_error, lat_arc_error, lon_arc_error, lon_arc2_error
     return area_error, lat_arc_error, lon_arc_error
+
+
+def metrics_error_columns(Ni, displaced_pole=-999):
+    """The dy columns OGG:739 / 755-760 sum: (Ni//4, none), or (pole, antipole) for a displaced pole."""
+    if displaced_pole == -999:
+        return Ni // 4, -1
+    antipole = displaced_pole + Ni // 2
+    if displaced_pole > Ni // 2:
+        antipole = displaced_pole - Ni // 2
+    return displaced_pole, antipole
+
+
+def metrics_error(dx_, dy_, area_, Ni, lat1, lat2=90, Re=_default_Re, bipolar=False, displaced_pole=-999,
+                  excluded_fraction=None):
+    """Self-check of OGG:732-770: a few host reductions over device-produced fields, compared with the sphere."""
+    col_a, col_b = metrics_error_columns(Ni, displaced_pole)
+    return metrics_error_from_sums(np.sum(area_), np.sum(dy_[:, col_a]), np.sum(dy_[:, col_b]) if col_b >= 0 else 0.0,
+                                   np.sum(dx_[0, :]), np.sum(dx_[-1, :]), lat1, lat2, Re, bipolar, displaced_pole, excluded_fraction)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -539,6 +539,60 @@ class Supergrid(object):
             out[k] = {"launches": len(ts), "total_ms": float(sum(ts)), "mean_ms": float(sum(ts) / len(ts))}
         return out
 
+    # -- self-check --------------------------------------------------------------------------------------------
+    def metrics_sums(self):
+        """Device tensor (n_subs, 7): the five sums of ogg_metrics_sums_dev over this rank's band of every sub-grid, then the
+        latitude of the sub-grid's first and of its last point row (each contributed by the one rank that owns that row)."""
+        torch, p, st = self.torch, self.plan, self._stream()
+        out = torch.zeros((len(p.subs), 7), dtype=torch.float64, device=self.device)
+        for k, s in enumerate(p.subs):
+            b = self.buf[s.name]
+            if b["n"] == 0:
+                continue
+            first, last = b["lo"] == 0, b["hi"] == s.nj1
+            col_a, col_b = ogg.metrics_error_columns(p.Ni, self._pole_column(s))
+            L.call("ogg_metrics_sums_dev", b["n"], b["n_cell"], p.Ni, b["dx"].data_ptr(), b["dy"].data_ptr() if b["n_cell"] else None,
+                   b["area"].data_ptr() if b["n_cell"] else None, col_a, col_b, int(first), int(last), out[k].data_ptr(), st)
+            if first:
+                out[k, 5].copy_(b["y"][0, 0])
+            if last:
+                out[k, 6].copy_(b["y"][b["n"] - 1, 0])
+        return out
+
+    def _pole_column(self, s):
+        if s.kind != "dpole":
+            return -999
+        return int(self.plan.Ni * np.mod(s.lon_dp - self.plan.lon0, 360) / 360.0)   # OGG:1160 poles_i
+
+    def metrics_error(self, sums=None):
+        """The reference's CHECK_metrics lines (OGG:732-770) for every sub-grid of a band-sharded run: % errors of sum(area), of a
+        meridian arc and of the parallel arc(s) against the sphere, from five sums per band taken on the device and ONE all-reduce
+        (RCCL) of n_subs x 7 doubles over the ranks -- the only collective of the default pipeline.  Returns {sub-grid name:
+        tuple as returned by the reference's metrics_error}.  ``sums``: precomputed metrics_sums() (tests)."""
+        torch, p = self.torch, self.plan
+        t = self.metrics_sums() if sums is None else sums
+        if self.world > 1:
+            if self.halo == "local":  # virtual ranks in one process
+                if sums is None:
+                    t = sum(g.metrics_sums() for g in self.peers if g is not self) + t
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(t)
+        v = t.cpu().numpy()
+        out = {}
+        for k, s in enumerate(p.subs):
+            area, dy_a, dy_b, dx_first, dx_last, lat_first, lat_last = (float(x) for x in v[k])
+            if s.kind == "bipolar":
+                out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, s.lat0_bp, 90.0, p.Re, bipolar=True)
+            elif s.kind == "dpole":  # OGG:1161; with the doughnut rows skipped the area and dy sums are partial, as the reference warns
+                out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, s.lat0, -90.0, p.Re,
+                                                          displaced_pole=self._pole_column(s))
+            elif s.name == "SC":     # regular southern cap, OGG:1146: (phiSC[-1, 0], phiSC[0, 0])
+                out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, lat_last, lat_first, p.Re)
+            else:                    # Mercator, Southern Ocean: (phi[0, 0], phi[-1, 0])
+                out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, lat_first, lat_last, p.Re)
+        return out
+
     # -- results ---------------------------------------------------------------------------------------------
     def bands_to_host(self):
         """This rank's bands as numpy arrays (halo rows dropped): {sub: {field: array}}."""

@@ -59,6 +59,34 @@ def _worker(rank, world, port, r, q):
                 ok &= np.array_equal(dx[: b["n"]], full[s.name][2][b["lo"]:b["hi"]])
                 ok &= np.array_equal(dy[: b["n_cell"]], full[s.name][3][b["lo"]:b["lo"] + b["n_cell"]])
                 ok &= np.array_equal(area[: b["n_cell"]], full[s.name][4][b["lo"]:b["lo"] + b["n_cell"]])
+        # metrics_error of a band-sharded run: per-band sums (formed here on the host from the oracle's fields, on a GPU by
+        # ogg_metrics_sums_dev), one all-reduce, the reference's formulas -- against the reference's function on whole sub-grids
+        import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+        sums = torch.zeros((len(plan.subs), 7), dtype=torch.float64)
+        for k, s in enumerate(plan.subs):
+            b = g.buf[s.name]
+            if b["n"] == 0:
+                continue
+            y_full, dx_f, dy_f, ar_f = (full[s.name][i] for i in (1, 2, 3, 4))
+            ca, cb = ogg.metrics_error_columns(plan.Ni, g._pole_column(s))
+            cells = slice(b["lo"], b["lo"] + b["n_cell"])
+            sums[k, 0] = ar_f[cells].sum()
+            sums[k, 1] = dy_f[cells, ca].sum()
+            sums[k, 2] = dy_f[cells, cb].sum() if cb >= 0 else 0.0
+            if b["lo"] == 0:
+                sums[k, 3], sums[k, 5] = dx_f[0].sum(), y_full[0, 0]
+            if b["hi"] == s.nj1:
+                sums[k, 4], sums[k, 6] = dx_f[-1].sum(), y_full[-1, 0]
+        got = g.metrics_error(sums=sums)
+        for s in plan.subs:
+            y_full, dx_f, dy_f, ar_f = (full[s.name][i] for i in (1, 2, 3, 4))
+            if s.kind == "bipolar":
+                want = orc.metrics_error(dx_f, dy_f, ar_f, plan.Ni, s.lat0_bp, 90.0, bipolar=True)
+            elif s.name == "SC":
+                want = orc.metrics_error(dx_f, dy_f, ar_f, plan.Ni, y_full[-1, 0], y_full[0, 0])
+            else:
+                want = orc.metrics_error(dx_f, dy_f, ar_f, plan.Ni, y_full[0, 0], y_full[-1, 0])
+            ok &= len(got[s.name]) == len(want) and all(abs(a - b) < 1e-9 for a, b in zip(got[s.name], want))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -174,6 +174,37 @@ def test_bench_json_contract(tmp_path):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cells/s" and c["sample"]
 
 
+@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r0.5_dp", "r0.5_latdp"])
+@pytest.mark.parametrize("world", [1, 3])
+def test_metrics_error_on_device(sg, name, world):
+    """Supergrid.metrics_error (five device sums per band + one sum over the ranks) against the reference's function
+    (oracle restatement) applied to the whole sub-grid arrays."""
+    import torch
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    ranks = []
+    for r in range(world):
+        ranks.append(sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo="local", peers=ranks, latlon="fused"))
+    for g in ranks:
+        g.step()
+    torch.cuda.synchronize()
+    got = ranks[0].metrics_error()
+    bands = [g.bands_to_host() for g in ranks]
+    for s in plan.subs:
+        f = {k: np.concatenate([b[s.name][k] for b in bands]) for k in ("y", "dx", "dy", "area")}
+        if s.kind == "bipolar":
+            want = orc.metrics_error(f["dx"], f["dy"], f["area"], plan.Ni, s.lat0_bp, 90.0, bipolar=True)
+        elif s.kind == "dpole":
+            want = orc.metrics_error(f["dx"], f["dy"], f["area"], plan.Ni, s.lat0, -90.0, displaced_pole=ranks[0]._pole_column(s))
+        elif s.name == "SC":
+            want = orc.metrics_error(f["dx"], f["dy"], f["area"], plan.Ni, f["y"][-1, 0], f["y"][0, 0])
+        else:
+            want = orc.metrics_error(f["dx"], f["dy"], f["area"], plan.Ni, f["y"][0, 0], f["y"][-1, 0])
+        assert len(got[s.name]) == len(want)
+        assert all(abs(a - b) < 1e-9 for a, b in zip(got[s.name], want)), (s.name, got[s.name], want)
+        if s.kind in ("mercator", "latlon", "bipolar"):
+            assert max(abs(e) for e in got[s.name]) < 0.05, (s.name, got[s.name])   # the grids are accurate: errors in %
+
+
 def test_more_ranks_than_rows(sg):
     """Tiny sub-grids: some ranks own no rows of a sub-grid, the top band may own only the fold row."""
     plan = sg.SupergridPlan(0.25, ensure_nj_even=True)
