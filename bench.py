@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--as-world", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="run the caps on side streams next to the lat-lon sub-grids")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
+    ap.add_argument("--d2h", type=int, default=1, help="after the timed region: time the copy of this rank's bands to pinned host memory (information)")
     ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
                     help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
@@ -260,6 +261,23 @@ def main():
                 self_check = {k: [float(e) for e in v] for k, v in sg.metrics_error().items()}
         except Exception as exc:  # never lose the bench line over the self-check
             self_check = {"error": repr(exc)}
+    # for information (SURVEY 8d ii): this rank's bands copied to pinned host memory, after the pass
+    d2h = None
+    if args.d2h:
+        try:
+            pinned = [(b[f], torch.empty(b[f].shape, dtype=b[f].dtype, pin_memory=True)) for b in sg.buf.values() for f in supergrid.FIELDS]
+            for _ in range(2):
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                for dev, host in pinned:
+                    host.copy_(dev, non_blocking=True)
+                torch.cuda.synchronize()
+                td = time.perf_counter() - td
+            nbytes = sum(dev.numel() * 8 for dev, _ in pinned)
+            d2h = {"ms": td * 1e3, "bytes": nbytes, "GBps": nbytes / td / 1e9}
+            del pinned
+        except Exception as exc:
+            d2h = {"error": repr(exc)}
     # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
     # stream (events cannot be read back from inside a replayed graph)
     timed_launch = "%s%s%s" % (sg.launch, ", caps on side streams" if (sg.launch == "kernels" and sg.overlap) else (", displaced-pole cap on a side stream" if (sg.overlap and has_dp) else ""),
@@ -322,6 +340,7 @@ def main():
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": roof, "pass_launches": launches,
             "self_check_metrics_error_percent": self_check,
+            "d2h_pinned_after_pass": d2h,
             "kernels": kernels,
         }
         if world == 1 and args.cpu_sample_div > 0:
