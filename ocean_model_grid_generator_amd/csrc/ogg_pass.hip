@@ -61,7 +61,7 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
 struct PassBParams {
     FusedParams ll;
     LatlonShare share;
-    MeshParams mesh;        // layout "tb": the cap mesh runs here, next to the quadrature, and launch A only builds the tables
+    MeshParams mesh;        // the cap mesh runs here, next to the quadrature; launch A only builds the tables
     long mesh_gx, n_mesh;
     QuadParams q;
     QuadRange guard, fast;
@@ -162,34 +162,21 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.gx * qp.guard.gy : 0;
         B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.gx * qp.fast.gy : 0;
     }
-    // split of the lat-lon strips between the two launches: in proportion to their VALU time (per cap row, measured at
-    // 1/8 degree: mesh 1, plain quadrature 2.1, guarded quadrature 3.1)
-    long s1 = n_strips_ll;
+    // With metrics, launch A builds only the tables and launch B carries everything else, the cap mesh included: one long launch
+    // in which all three kinds of workgroup overlap (measured faster than mesh + part of the lat-lon strips in A at every share
+    // from 1 to 1/8 of the 1/8 degree grid).  Without metrics there is no launch B: A carries the lat-lon strips and the mesh.
     const bool launch_b = have_quad && (B.n_guard + B.n_fast > 0);
-    // Default layout: launch A builds only the tables and launch B carries everything else, the cap mesh included -- one
-    // long launch in which all three kinds of workgroup overlap (measured faster than mesh + part of the lat-lon strips in A
-    // at every share from 1 to 1/8 of the 1/8 degree grid).  OGG_PASS_LAYOUT=ab selects that older split.
-    const char* lay = getenv("OGG_PASS_LAYOUT");
-    const bool layout_tb = launch_b && !(lay && lay[0] == 'a');
-    if (layout_tb) {
+    const long s1 = launch_b ? 0 : n_strips_ll;   // lat-lon strips [0, s1) in launch A, [s1, S) in launch B
+    if (launch_b) {
         B.mesh = A.mesh, B.mesh_gx = A.mesh_gx, B.n_mesh = A.n_mesh;
         A.n_mesh = 0;
-        s1 = 0;
-    } else if (launch_b) {
-        const double ta = have_cap ? (double)cap->n_pt_rows : 0.0;
-        const double tb = (qp.has_fast ? 2.1 * (double)(qp.fast.row_end - qp.fast.row_begin) : 0.0) +
-                          (qp.has_guard ? 3.1 * (double)(qp.guard.row_end - qp.guard.row_begin) : 0.0);
-        double f = ta / (ta + tb);
-        if (const char* e = getenv("OGG_PASS_SPLIT")) f = atof(e);
-        s1 = (long)llround(f * (double)n_strips_ll);
-        s1 = s1 < 0 ? 0 : (s1 > n_strips_ll ? n_strips_ll : s1);
     }
     if (alg_bytes3) {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
         const double ni = (double)(ni1 - 1);
         const double mesh_bytes = have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0;
-        alg_bytes3[0] = latlon_strip_bytes(ll, 0, s1) + (layout_tb ? 0.0 : mesh_bytes);
+        alg_bytes3[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes);
         alg_bytes3[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) +
-                                       (layout_tb ? mesh_bytes : 0.0)
+                                       mesh_bytes
                                  : 0.0;
         alg_bytes3[2] = (have_quad && qp.has_top) ? 8.0 * ni : 0.0;
     }

@@ -20,7 +20,7 @@ ap.add_argument("--as-world", type=int, default=1)
 ap.add_argument("--workload", default="r8")
 ap.add_argument("--wg", default="115,160,230,320,460")
 ap.add_argument("--wg-small", default="")
-ap.add_argument("--split", default="0.2,0.3,0.4")
+ap.add_argument("--split", default="auto")
 ap.add_argument("--steps", type=int, default=50)
 args = ap.parse_args()
 plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
@@ -47,10 +47,6 @@ def timeit():
 
 
 print("default: %.4f ms" % timeit(), timeit.launches)
-for lay in ("ab", "tb", "ab", "tb"):
-    os.environ["OGG_PASS_LAYOUT"] = lay
-    print("layout %s: %.4f ms" % (lay, timeit()), timeit.launches, flush=True)
-os.environ.pop("OGG_PASS_LAYOUT")
 key = "OGG_PASS_LL_WG_SMALL" if args.wg_small else "OGG_PASS_LL_WG"
 wgs = (args.wg_small or args.wg).split(",")
 for wg, sp in itertools.product(wgs, args.split.split(",")):
