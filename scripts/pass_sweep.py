@@ -3,7 +3,6 @@
 usage: python scripts/pass_sweep.py [--as-rank R --as-world W] [--workload r8]
 """
 import argparse
-import itertools
 import os
 import sys
 import time
@@ -18,9 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--as-rank", type=int, default=0)
 ap.add_argument("--as-world", type=int, default=1)
 ap.add_argument("--workload", default="r8")
-ap.add_argument("--wg", default="115,160,230,320,460")
+ap.add_argument("--wg", default="36,48,60,84,120")
 ap.add_argument("--wg-small", default="")
-ap.add_argument("--split", default="auto")
 ap.add_argument("--steps", type=int, default=50)
 args = ap.parse_args()
 plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
@@ -49,10 +47,6 @@ def timeit():
 print("default: %.4f ms" % timeit(), timeit.launches)
 key = "OGG_PASS_LL_WG_SMALL" if args.wg_small else "OGG_PASS_LL_WG"
 wgs = (args.wg_small or args.wg).split(",")
-for wg, sp in itertools.product(wgs, args.split.split(",")):
+for wg in wgs:
     os.environ[key] = wg
-    if sp == "auto":
-        os.environ.pop("OGG_PASS_SPLIT", None)
-    else:
-        os.environ["OGG_PASS_SPLIT"] = sp
-    print("%s=%s split=%s: %.4f ms" % (key, wg, sp, timeit()), timeit.launches, flush=True)
+    print("%s=%s: %.4f ms" % (key, wg, timeit()), timeit.launches, flush=True)
