@@ -274,3 +274,34 @@ def test_full_size_properties_r8(sg):
     jM = sub["SC"]["y"].shape[0] + sub["SO"]["y"].shape[0] + sub["Merc"]["y"].shape[0] - 3
     col = g["dy"][:, Ni // 4]
     assert abs(col[jM] / col[jM - 1] - 1) < 0.02
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (8, 7)])
+def test_full_size_properties_r16_on_device(sg, world, rank):
+    """BASELINE config 5 (1/16 degree, 101 M cells, 4.9 GB of fields) through the fused pass, checked where the fields are:
+    the reference's analytic-sphere self-check from device sums, signs, monotone latitude, the joints."""
+    import torch
+    plan = sg.SupergridPlan(16.0)
+    assert (plan.nyp, plan.Ni + 1) == (8785, 11521) and plan.cells == 8784 * 11520
+    g = sg.Supergrid(plan, rank=rank, world=world, device="cuda:0", halo="recompute")
+    assert g.launch == "pass"
+    g.step()
+    torch.cuda.synchronize()
+    q = plan.Ni // 4
+    for s in plan.subs:
+        b = g.buf[s.name]
+        if b["n"] == 0:
+            continue
+        assert bool(torch.all(b["dx"] > 0)) and bool(torch.all(b["dy"] >= 0)) and bool(torch.all(b["area"] > 0)), s.name
+        assert bool(torch.all(torch.abs(b["angle_dx"]) <= 180.0)), s.name
+        ycol = b["y"][: b["n"], q]
+        assert bool(torch.all(ycol[1:] > ycol[:-1])), s.name
+    if world == 1:
+        err = g.metrics_error()
+        for name, e in err.items():
+            assert max(abs(v) for v in e) < 1e-9, (name, e)
+        sums = g.metrics_sums().cpu().numpy()
+        assert abs(sums[:, 0].sum() / (4 * np.pi * 6371.0e3 ** 2) - 1) < 1e-12
+        ys = {s.name: (float(g.buf[s.name]["y"][0, q]), float(g.buf[s.name]["y"][g.buf[s.name]["n"] - 1, q])) for s in plan.subs}
+        assert ys["SC"][0] == -90.0 and ys["BP"][1] == 90.0
+        assert ys["SC"][1] == ys["SO"][0] and ys["SO"][1] == ys["Merc"][0] and ys["Merc"][1] == ys["BP"][0]
