@@ -103,10 +103,10 @@ OGG_DEV double great_arc(double lam0d, double phi0d, double lam1d, double phi1d)
 
 
 // ---- monotonic_bounding (OGG:470-475) as a workgroup-wide scan of 1-bit maps ------------------------------------
-template <int NP>
+template <int NP, int TX = SW_TX>
 struct UnwrapShared {
-    double v[NP][SW_TX];
-    unsigned w0[SW_WAVES], w1[SW_WAVES];
+    double v[NP][TX];
+    unsigned w0[TX / 64], w1[TX / 64];
 };
 
 // Packed "was lowered by 360" states of this thread's column for NP independent scans.  v: raw values of this
@@ -114,9 +114,9 @@ struct UnwrapShared {
 // carry_v / carry_state_ptr: raw values and states of the column just before this chunk (LDS; the caller rewrites
 // them only AFTER this function returns).  Contains two workgroup barriers: every thread of the workgroup must call it
 // (inactive threads contribute the identity map).
-template <int NP>
+template <int NP, int TX = SW_TX>
 OGG_DEV unsigned unwrap_states(const double* v, bool active, bool first_col, const double* seed, const double* carry_v,
-                               const unsigned* carry_state_ptr, UnwrapShared<NP>& sh) {
+                               const unsigned* carry_state_ptr, UnwrapShared<NP, TX>& sh) {
     constexpr unsigned ALL = (NP >= 32) ? 0xffffffffu : ((1u << NP) - 1u);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -186,9 +186,13 @@ OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
     return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
 }
 
-// ---- mesh (OGG:488-518): one workgroup per row, chunks of SW_TX columns, exact unwrap -------------------------------
-__global__ __launch_bounds__(SW_TX) void dpole_mesh_kernel(SweepParams p) {
-    __shared__ UnwrapShared<1> s_u;
+// ---- mesh (OGG:488-518): one workgroup per row, chunks of TX columns, exact unwrap -----------------------------------
+// The chunks of a row are a sequential chain (two barriers each), so the row time is ~n_cols / TX chunk latencies whatever
+// the number of rows: a band of a few rows (one rank's share on 8 GPUs) gains nothing from the idle CUs.  Hence the large
+// workgroup: 1024 threads when the launch would not fill the chip anyway, 256 for many rows.
+template <int TX>
+__global__ __launch_bounds__(TX) void dpole_mesh_kernel(SweepParams p) {
+    __shared__ UnwrapShared<1, TX> s_u;
     __shared__ double s_carry_v[1];
     __shared__ unsigned s_carry_state;
     const int tid = threadIdx.x;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(SW_TX) void dpole_mesh_kernel(SweepParams p) {
     const double r = dp_row_radius(jv, p, c);                              // row-only
     const double i_first = p.i_arr ? p.i_arr[0] : 0.0;
     const double seed[1] = {p.lon0 + (i_first * 360.0) / (double)p.ni};    // lon_grid[0,0] (OGG:463)
-    for (long c0 = 0; c0 < p.n_cols; c0 += SW_TX) {
+    for (long c0 = 0; c0 < p.n_cols; c0 += TX) {
         const long g = c0 + tid;
         const bool active = g < p.n_cols;
         double v[1] = {0.0}, ph = 0.0;
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(SW_TX) void dpole_mesh_kernel(SweepParams p) {
             const double iv = p.i_arr ? p.i_arr[g] : (double)g;
             dp_point(r, dp_column(iv, p, c), c, v[0], ph);
         }
-        const unsigned st = unwrap_states<1>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
-        if (active && tid == SW_TX - 1) {
+        const unsigned st = unwrap_states<1, TX>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
+        if (active && tid == TX - 1) {
             s_carry_v[0] = v[0];
             s_carry_state = st;
         }
@@ -528,7 +532,14 @@ __global__ __launch_bounds__(SW_TX) void dpole_direct_kernel(DirectParams p) {
 
 int launch_mesh(const SweepParams& p, long blocks, hipStream_t s) {
     if (blocks <= 0) return OGG_OK;
-    dpole_mesh_kernel<<<(unsigned)blocks, SW_TX, 0, s>>>(p);
+    long tx = (blocks >= 1024) ? 256 : ((blocks >= 384) ? 512 : 1024);
+    if (const char* e = getenv("OGG_DP_MESH_TX")) tx = atol(e);
+    if (tx >= 1024)
+        dpole_mesh_kernel<1024><<<(unsigned)blocks, 1024, 0, s>>>(p);
+    else if (tx >= 512)
+        dpole_mesh_kernel<512><<<(unsigned)blocks, 512, 0, s>>>(p);
+    else
+        dpole_mesh_kernel<256><<<(unsigned)blocks, 256, 0, s>>>(p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }
