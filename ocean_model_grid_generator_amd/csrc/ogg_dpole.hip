@@ -369,35 +369,34 @@ __global__ void dpole_chord_tables_kernel(ChordParams p) {
     }
 }
 
-struct Vec3 {
-    double x, y, z;
+struct Gno {
+    double X, Y;   // gnomonic image (plane tangent at the south pole) of a point of the sphere
 };
 
-// unit vector of the point whose gnomonic image (plane tangent at the south pole) is w * r_joint, w the conformal image of
-// the probe (OGG:454-455).  The complex quotient is formed with one Newton reciprocal of |den|^2 and the normalisation with a
-// Newton rsqrt (<= 2 ulp each): the chord between two such vectors is accurate to ~1e-16 / 2e-6 either way.
-OGG_DEV Vec3 dp_unit(double r, cplx ep, const DpConst& c) {
-    const cplx z = {r * ep.re, r * ep.im};
-    const cplx num = {z.re + c.z0r, z.im + c.z0i};
-    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, z);
-    const cplx den = {1 + cz.re, cz.im};
-    const double inv = rcp_nr(den.re * den.re + den.im * den.im);
-    const double wre = (num.re * den.re + num.im * den.im) * inv;
-    const double wim = (num.im * den.re - num.re * den.im) * inv;
-    const double X = wre * c.r_joint, Y = wim * c.r_joint;
-    const double n = rsqrt_nr(X * X + Y * Y + 1.0);
-    return Vec3{X * n, Y * n, -n};
+// w * r_joint, w the conformal image of the probe (OGG:454-455), with the complex quotient formed from one Newton reciprocal
+// of |den|^2 (<= 2 ulp): the point of the sphere is (X, Y, -1) / sqrt(1 + X^2 + Y^2).
+OGG_DEV Gno dp_gnomonic(double r, cplx ep, const DpConst& c) {
+    const double zr = r * ep.re, zi = r * ep.im;
+    const double nr = zr + c.z0r, ni = zi + c.z0i;
+    const double dr = 1 + fma(c.z0r, zr, c.z0i * zi);      // 1 + conj(z0) z
+    const double di = fma(c.z0r, zi, -(c.z0i * zr));
+    const double s = rcp_nr(fma(dr, dr, di * di)) * c.r_joint;
+    return Gno{fma(nr, dr, ni * di) * s, fma(ni, dr, -(nr * di)) * s};
 }
 
-OGG_DEV double chord_arc(const Vec3& a, const Vec3& b) {
-    const double dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
-    const double c2 = dx * dx + dy * dy + dz * dz;
-    if (c2 == 0.0) return 0.0;
-    const double half = 0.5 * sqrt_nr(c2);
-    // 2 asin(half): the probes are ~1e-6 apart, where three terms of the series are exact to 1e-30; far-apart points
-    // (never produced by the eps = 1e-3 stencil) take the library function
-    const double h2 = half * half;
-    return (half < 1e-3) ? 2.0 * (half * (1.0 + h2 * (1.0 / 6.0 + h2 * (3.0 / 40.0)))) : 2.0 * asin(half);
+// Great-arc distance of two nearby points from their gnomonic images a, b: with p = (X, Y, -1),
+//   sin(theta) = |pa x pb| / (|pa| |pb|),   |pa x pb|^2 = dX^2 + dY^2 + (Xa dY - Ya dX)^2,   |p|^2 = 1 + X^2 + Y^2
+// -- the differences dX, dY are formed once, nothing is normalised per point, and theta = asin(sin theta) from three terms of
+// the series (the probes of the eps = 1e-3 stencil are ~1e-6 rad apart; exact to 1e-30 below 1e-3).
+OGG_DEV double gnomonic_arc(const Gno& a, const Gno& b) {
+    const double dX = b.X - a.X, dY = b.Y - a.Y;
+    const double cr = fma(a.X, dY, -(a.Y * dX));
+    const double s2 = fma(dX, dX, fma(dY, dY, cr * cr));
+    if (s2 == 0.0) return 0.0;
+    const double na = fma(a.X, a.X, fma(a.Y, a.Y, 1.0)), nb = fma(b.X, b.X, fma(b.Y, b.Y, 1.0));
+    const double q = s2 * rcp_nr(na * nb);            // sin^2(theta)
+    const double sn = sqrt_nr(q);
+    return (sn < 1e-3) ? sn * (1.0 + q * (1.0 / 6.0 + q * (3.0 / 40.0))) : asin(sn);
 }
 
 template <int F>
@@ -421,8 +420,8 @@ __global__ __launch_bounds__(256) void dpole_chord_h_kernel(ChordParams p) {
 #pragma unroll
     for (int m = 1; m <= H; ++m) {
         // OGG:538,541: ds(j, i + m eps, j, i - m eps);  OGG:553,556: ds(j + m eps, i, j - m eps, i)
-        dsi[m - 1] = chord_arc(dp_unit(r[0], ep[2 * m - 1], c), dp_unit(r[0], ep[2 * m], c));
-        dsj[m - 1] = chord_arc(dp_unit(r[2 * m - 1], ep[0], c), dp_unit(r[2 * m], ep[0], c));
+        dsi[m - 1] = gnomonic_arc(dp_gnomonic(r[0], ep[2 * m - 1], c), dp_gnomonic(r[0], ep[2 * m], c));
+        dsj[m - 1] = gnomonic_arc(dp_gnomonic(r[2 * m - 1], ep[0], c), dp_gnomonic(r[2 * m], ep[0], c));
     }
     p.h_i[row * p.n_cols + col] = central_difference<F>(dsi, reps);
     if (p.h_j) p.h_j[row * p.n_cols + col] = central_difference<F>(dsj, reps);
