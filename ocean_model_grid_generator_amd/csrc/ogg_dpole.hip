@@ -318,10 +318,10 @@ __global__ __launch_bounds__(SW_TX) void dpole_h_kernel(HParams p) {
 // The reference differentiates great-arc distances numerically (OGG:535-562): h = (8 ds(eps) - ds(2 eps)) / (12 eps), where
 // ds is the haversine distance between two projected points that are ~2e-6 rad apart, formed from longitudes/latitudes in
 // degrees.  That subtraction of two O(1) angles loses 10 digits: against an 80-bit evaluation the reference's own h is
-// accurate to 2e-9 (relative).  Here the SAME stencil (the same 4H probe points, the same w = conformal image of each probe,
-// bit for bit as in dp_point) is kept, but the distance between two probes is taken from their unit vectors on the sphere,
-// ds = 2 asin(|u1 - u0| / 2): no atan2 / atan / hypot per probe, no sin/cos/asin per pair, and no longitude at all -- hence
-// no 360-degree unwrap and no sequential scan.  Its h is accurate to 8e-10 and differs from the reference's by 1.6e-9, i.e. by
+// accurate to 2e-9 (relative).  Here the SAME stencil (the same 4H probe points, the same w = conformal image of each probe)
+// is kept, but the distance between two probes is taken from their positions on the sphere -- from the gnomonic images
+// pa, pb = (X, Y, -1): sin(ds) = |pa x pb| / (|pa| |pb|), see gnomonic_arc -- : no atan2 / atan / hypot per probe, no
+// sin/cos/asin per pair, and no longitude at all -- hence no 360-degree unwrap and no sequential scan.  Its h is accurate to 8e-10 and differs from the reference's by 1.6e-9, i.e. by
 // less than the reference's own rounding error (tests/test_gpu_parity.py bounds it at 5e-7 like the literal path;
 // OGG_DP_LITERAL=1 selects the literal kernels, which numerical_hi / numerical_hj / great_arc_distance always use).
 struct ChordParams {
