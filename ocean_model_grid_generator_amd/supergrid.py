@@ -585,8 +585,11 @@ class Supergrid(object):
             if s.kind == "bipolar":
                 out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, s.lat0_bp, 90.0, p.Re, bipolar=True)
             elif s.kind == "dpole":  # OGG:1161; with the doughnut rows skipped the area and dy sums are partial, as the reference warns
-                out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, s.lat0, -90.0, p.Re,
-                                                          displaced_pole=self._pole_column(s))
+                e = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, s.lat0, -90.0, p.Re,
+                                                displaced_pole=self._pole_column(s))
+                if s.row0 > 0:  # doughnut rows are not generated: area and meridian arc cannot be estimated (OGG:762-763 says so)
+                    e = (float("nan"), float("nan"), e[2])
+                out[s.name] = e
             elif s.name == "SC":     # regular southern cap, OGG:1146: (phiSC[-1, 0], phiSC[0, 0])
                 out[s.name] = ogg.metrics_error_from_sums(area, dy_a, dy_b, dx_first, dx_last, lat_last, lat_first, p.Re)
             else:                    # Mercator, Southern Ocean: (phi[0, 0], phi[-1, 0])

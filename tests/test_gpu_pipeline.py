@@ -200,7 +200,9 @@ def test_metrics_error_on_device(sg, name, world):
         else:
             want = orc.metrics_error(f["dx"], f["dy"], f["area"], plan.Ni, f["y"][0, 0], f["y"][-1, 0])
         assert len(got[s.name]) == len(want)
-        assert all(abs(a - b) < 1e-9 for a, b in zip(got[s.name], want)), (s.name, got[s.name], want)
+        pairs = [(a, b) for a, b in zip(got[s.name], want) if a == a]   # NaN: not estimable without the doughnut rows (dpole)
+        assert len(pairs) == len(want) or s.kind == "dpole"
+        assert all(abs(a - b) < 1e-9 for a, b in pairs), (s.name, got[s.name], want)
         if s.kind in ("mercator", "latlon", "bipolar"):
             assert max(abs(e) for e in got[s.name]) < 0.05, (s.name, got[s.name])   # the grids are accurate: errors in %
 
