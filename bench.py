@@ -258,7 +258,7 @@ def main():
     if not plan.skip_metrics and args.self_check:
         try:
             if args.as_rank is None:
-                self_check = {k: [float(e) for e in v] for k, v in sg.metrics_error().items()}
+                self_check = {k: [None if e != e else float(e) for e in v] for k, v in sg.metrics_error().items()}  # NaN (not estimable) -> null
         except Exception as exc:  # never lose the bench line over the self-check
             self_check = {"error": repr(exc)}
     # for information (SURVEY 8d ii): this rank's bands copied to pinned host memory, after the pass
