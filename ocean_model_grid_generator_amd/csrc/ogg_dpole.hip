@@ -5,7 +5,7 @@
 //   displacedPoleCap_metrics_quad            OGG:565-601
 //
 // Kernels:
-//   dpole_mesh_kernel                    lam, phi on a lattice of (fractional) indices, exact 360-degree unwrap     -> K5
+//   dpole_eval_kernel + _unwrap_kernel   lam, phi on a lattice of (fractional) indices, exact 360-degree unwrap     -> K5
 //   dpole_direct_kernel                  displacedPoleCap_projection on explicit grids / bare monotonic_bounding
 //   dpole_h_kernel<F, group>             literal finite-difference scale factors h_i / h_j (numerical_hi / _hj)
 //   dpole_chord_tables / _h_kernel<F>    the same stencil with the chord form of the great-arc distance            -> K6
@@ -186,39 +186,53 @@ OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
     return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
 }
 
-// ---- mesh (OGG:488-518): one workgroup per row, chunks of TX columns, exact unwrap -----------------------------------
-// The chunks of a row are a sequential chain (two barriers each), so the row time is ~n_cols / TX chunk latencies whatever
-// the number of rows: a band of a few rows (one rank's share on 8 GPUs) gains nothing from the idle CUs.  Hence the large
-// workgroup: 1024 threads when the launch would not fill the chip anyway, 256 for many rows.
+// ---- mesh (OGG:488-518) in two launches ---------------------------------------------------------------------------------
+// The unwrap of a row is a sequential chain over its chunks, so a kernel that evaluates the projection inside that chain takes
+// n_cols / TX projection latencies per row whatever the number of rows -- a band of 36 rows (one rank's share on 8 GPUs) kept
+// 36 CUs busy for 28 us.  Hence: (1) every point's raw longitude and latitude, fully parallel (one workgroup per 256 columns
+// of a row); (2) the unwrap alone, one workgroup of 1024 threads per row reading the raw longitudes back (L2) and lowering them
+// in place.  Same arithmetic per point, same scan: the same bits as the one-kernel form.
+__global__ __launch_bounds__(SW_TX) void dpole_eval_kernel(SweepParams p) {
+    __shared__ DpConst s_c;
+    __shared__ double s_r;
+    const int tid = threadIdx.x;
+    const long row = blockIdx.y;
+    if (tid == 0) {
+        s_c = dp_const(p);
+        const double jv = p.j_arr ? p.j_arr[row] : (double)(p.j0 + row);
+        s_r = dp_row_radius(jv, p, s_c);                                   // row-only
+    }
+    __syncthreads();
+    const long g = (long)blockIdx.x * SW_TX + tid;
+    if (g >= p.n_cols) return;
+    const DpConst c = s_c;
+    const double iv = p.i_arr ? p.i_arr[g] : (double)g;
+    double lam_raw, ph;
+    dp_point(s_r, dp_column(iv, p, c), c, lam_raw, ph);
+    p.out0[row * p.n_cols + g] = lam_raw;
+    p.out1[row * p.n_cols + g] = ph;
+}
+
 template <int TX>
-__global__ __launch_bounds__(TX) void dpole_mesh_kernel(SweepParams p) {
+__global__ __launch_bounds__(TX) void dpole_unwrap_kernel(SweepParams p) {
     __shared__ UnwrapShared<1, TX> s_u;
     __shared__ double s_carry_v[1];
     __shared__ unsigned s_carry_state;
     const int tid = threadIdx.x;
     const long row = blockIdx.x;
-    const DpConst c = dp_const(p);
-    const double jv = p.j_arr ? p.j_arr[row] : (double)(p.j0 + row);
-    const double r = dp_row_radius(jv, p, c);                              // row-only
     const double i_first = p.i_arr ? p.i_arr[0] : 0.0;
     const double seed[1] = {p.lon0 + (i_first * 360.0) / (double)p.ni};    // lon_grid[0,0] (OGG:463)
+    double* lam = p.out0 + row * p.n_cols;
     for (long c0 = 0; c0 < p.n_cols; c0 += TX) {
         const long g = c0 + tid;
         const bool active = g < p.n_cols;
-        double v[1] = {0.0}, ph = 0.0;
-        if (active) {
-            const double iv = p.i_arr ? p.i_arr[g] : (double)g;
-            dp_point(r, dp_column(iv, p, c), c, v[0], ph);
-        }
+        double v[1] = {active ? lam[g] : 0.0};
         const unsigned st = unwrap_states<1, TX>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
         if (active && tid == TX - 1) {
             s_carry_v[0] = v[0];
             s_carry_state = st;
         }
-        if (active) {
-            p.out0[row * p.n_cols + g] = (st & 1u) ? v[0] - 360 : v[0];    // OGG:473
-            p.out1[row * p.n_cols + g] = ph;
-        }
+        if (active && (st & 1u)) lam[g] = v[0] - 360;                      // OGG:473
     }
 }
 
@@ -529,16 +543,11 @@ __global__ __launch_bounds__(SW_TX) void dpole_direct_kernel(DirectParams p) {
     }
 }
 
-int launch_mesh(const SweepParams& p, long blocks, hipStream_t s) {
-    if (blocks <= 0) return OGG_OK;
-    long tx = (blocks >= 1024) ? 256 : ((blocks >= 384) ? 512 : 1024);
-    if (const char* e = getenv("OGG_DP_MESH_TX")) tx = atol(e);
-    if (tx >= 1024)
-        dpole_mesh_kernel<1024><<<(unsigned)blocks, 1024, 0, s>>>(p);
-    else if (tx >= 512)
-        dpole_mesh_kernel<512><<<(unsigned)blocks, 512, 0, s>>>(p);
-    else
-        dpole_mesh_kernel<256><<<(unsigned)blocks, 256, 0, s>>>(p);
+int launch_mesh(const SweepParams& p, long rows, hipStream_t s) {
+    if (rows <= 0) return OGG_OK;
+    dpole_eval_kernel<<<dim3((unsigned)((p.n_cols + SW_TX - 1) / SW_TX), (unsigned)rows), SW_TX, 0, s>>>(p);
+    OGG_LAUNCH_CHECK();
+    dpole_unwrap_kernel<1024><<<(unsigned)rows, 1024, 0, s>>>(p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHORT = [("pass_a_kernel", "pass_a"), ("pass_b_kernel", "pass_b"), ("bipolar_quad_tail_kernel", "pass_tail"),
          ("bipolar_quad_kernel", "bipolar_quad"), ("bipolar_tables_kernel", "bipolar_quad"), ("midas_angle_kernel<true", "midas_angle"),
          ("midas_angle_kernel<false", "angle_x"), ("bipolar_mesh_kernel", "bipolar_mesh"), ("tile_latlon_kernel", "tile_latlon"),
-         ("dpole_mesh_kernel", "dpole_mesh"), ("dpole_chord", "dpole_quad"), ("dpole_h_kernel", "dpole_quad"), ("dpole_quad_reduce_kernel", "dpole_quad"),
+         ("dpole_eval_kernel", "dpole_mesh"), ("dpole_unwrap_kernel", "dpole_mesh"), ("dpole_chord", "dpole_quad"), ("dpole_h_kernel", "dpole_quad"), ("dpole_quad_reduce_kernel", "dpole_quad"),
          ("latlon_fused_kernel", "latlon_fused")]
 
 
