@@ -213,26 +213,69 @@ __global__ __launch_bounds__(SW_TX) void dpole_eval_kernel(SweepParams p) {
     p.out1[row * p.n_cols + g] = ph;
 }
 
+// Unwrap of one row by one workgroup in ONE step: thread t owns the CPT consecutive columns t*CPT .. and composes their
+// 1-bit maps sequentially (both incoming states), a wave64 shuffle scan and a scan over the waves give every thread its
+// incoming state, and a second sequential walk lowers its columns.  Two barriers per row instead of two per 1024 columns.
 template <int TX>
-__global__ __launch_bounds__(TX) void dpole_unwrap_kernel(SweepParams p) {
-    __shared__ UnwrapShared<1, TX> s_u;
-    __shared__ double s_carry_v[1];
-    __shared__ unsigned s_carry_state;
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(TX) void dpole_unwrap_kernel(SweepParams p, int cpt) {
+    __shared__ unsigned s_w0[TX / 64], s_w1[TX / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row = blockIdx.x;
     const double i_first = p.i_arr ? p.i_arr[0] : 0.0;
-    const double seed[1] = {p.lon0 + (i_first * 360.0) / (double)p.ni};    // lon_grid[0,0] (OGG:463)
+    const double seed = p.lon0 + (i_first * 360.0) / (double)p.ni;         // lon_grid[0,0] (OGG:463)
     double* lam = p.out0 + row * p.n_cols;
-    for (long c0 = 0; c0 < p.n_cols; c0 += TX) {
-        const long g = c0 + tid;
-        const bool active = g < p.n_cols;
-        double v[1] = {active ? lam[g] : 0.0};
-        const unsigned st = unwrap_states<1, TX>(v, active, g == 0, seed, s_carry_v, &s_carry_state, s_u);
-        if (active && tid == TX - 1) {
-            s_carry_v[0] = v[0];
-            s_carry_state = st;
+    const long g0 = (long)tid * cpt;
+    const long g1 = (g0 + cpt < p.n_cols) ? g0 + cpt : p.n_cols;
+    // f0 / f1: state after this thread's columns when the column before them was not / was lowered (identity if it owns none)
+    unsigned f0 = 0u, f1 = 1u;
+    if (g0 < g1) {
+        unsigned s0 = 0u, s1 = 1u;
+        double prev = (g0 > 0) ? lam[g0 - 1] : 0.0;
+        for (long g = g0; g < g1; ++g) {
+            const double v = lam[g];
+            if (g == 0) {
+                s0 = s1 = (v - seed > 100) ? 1u : 0u;                      // OGG:471-472: compared with x_0, no incoming state
+            } else {
+                s0 = (v - (s0 ? prev - 360 : prev) > 100) ? 1u : 0u;       // OGG:473-474: x_im1 is the ADJUSTED previous column
+                s1 = (v - (s1 ? prev - 360 : prev) > 100) ? 1u : 0u;
+            }
+            prev = v;
         }
-        if (active && (st & 1u)) lam[g] = v[0] - 360;                      // OGG:473
+        f0 = s0, f1 = s1;
+    }
+    // inclusive scan of the composition (later o earlier) over the wave, then over the waves
+    unsigned c0 = f0, c1 = f1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned e0 = __shfl_up(c0, off), e1 = __shfl_up(c1, off);
+        if (lane >= off) {
+            const unsigned h0 = e0 ? c1 : c0, h1 = e1 ? c1 : c0;
+            c0 = h0, c1 = h1;
+        }
+    }
+    if (lane == 63) s_w0[wave] = c0, s_w1[wave] = c1;
+    __syncthreads();
+    unsigned st = 0u;  // state of the column before this WAVE's first column (row start: no previous column, value unused)
+    for (int w = 0; w < wave; ++w) st = st ? s_w1[w] : s_w0[w];
+    // exclusive within the wave: state after the previous lane's columns
+    const unsigned p0 = __shfl_up(c0, 1), p1 = __shfl_up(c1, 1);
+    unsigned s_in = (lane == 0) ? st : (st ? p1 : p0);
+    const double prev0 = (g0 > 0 && g0 < g1) ? lam[g0 - 1] : 0.0;
+    __syncthreads();   // every thread has read its left neighbour's raw value before anybody lowers one (uniform barrier)
+    if (g0 < g1) {
+        double prev = prev0;
+        unsigned sp = s_in;
+        for (long g = g0; g < g1; ++g) {
+            const double v = lam[g];
+            unsigned sc;
+            if (g == 0)
+                sc = (v - seed > 100) ? 1u : 0u;
+            else
+                sc = (v - (sp ? prev - 360 : prev) > 100) ? 1u : 0u;
+            if (sc) lam[g] = v - 360;                                      // OGG:473
+            prev = v;
+            sp = sc;
+        }
     }
 }
 
@@ -547,7 +590,8 @@ int launch_mesh(const SweepParams& p, long rows, hipStream_t s) {
     if (rows <= 0) return OGG_OK;
     dpole_eval_kernel<<<dim3((unsigned)((p.n_cols + SW_TX - 1) / SW_TX), (unsigned)rows), SW_TX, 0, s>>>(p);
     OGG_LAUNCH_CHECK();
-    dpole_unwrap_kernel<1024><<<(unsigned)rows, 1024, 0, s>>>(p);
+    const int cpt = (int)((p.n_cols + 1023) / 1024);
+    dpole_unwrap_kernel<1024><<<(unsigned)rows, 1024, 0, s>>>(p, cpt);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }
