@@ -8,9 +8,10 @@ extern "C" int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band
     if (int e = plan_latlon(n_bands, bands, ni1, lon0, lenlon, Re, metrics, p, points)) return e;
     if (p.n_bands == 0) return OGG_OK;
     const long gx = latlon_gx(ni1);
-    // Resident workgroups: ~115 (measured: 92 already slow the kernel by 20 %, 69 by 60 %) saturate the HBM write path on a large launch (measured), which leaves the CUs to a
-    // concurrent VALU-bound kernel; small launches are latency-bound and take the whole chip.
-    long max_wg = points >= 8000000 ? 115 : (points >= 2000000 ? 512 : 2048);
+    // Resident workgroups (each owns 512 columns and walks its row strips grid-stride): the write path saturates with 60-100 of
+    // them and MORE are slower (1/8 degree, 19.8 M points: 60 -> 4.6 TB/s, 96 -> 4.45, 512 -> 4.16, 2048 -> 4.0; 1/16 degree: best
+    // at 96-144); small launches are latency-bound and want a few hundred.
+    long max_wg = points >= 8000000 ? 96 : 240;
     if (const char* e = getenv("OGG_FUSED_MAX_WG")) max_wg = atol(e);
     long gy = p.strip0[p.n_bands];
     if (gx * gy > max_wg) gy = (max_wg + gx - 1) / gx;
