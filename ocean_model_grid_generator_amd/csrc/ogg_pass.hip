@@ -11,8 +11,9 @@
 // (without metrics there is no quadrature: launch A then carries the lat-lon strips and the mesh, and B, C do not exist)
 //
 // The lat-lon workgroups come first in the index space (they are resident from the start and walk their strips grid-stride
-// while the compute workgroups stream through the remaining slots).  Every workgroup runs the same body function as the stand-alone kernels of
-// ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level entry points.
+// while the compute workgroups stream through the remaining slots).  Every workgroup runs the same body function as the
+// stand-alone kernels of ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level
+// entry points.
 #include "ogg_bipolar_dev.h"
 #include "ogg_latlon_fused_dev.h"
 
