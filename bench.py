@@ -237,10 +237,10 @@ def main():
         sg.capture()
         sg.replay()  # one untimed replay
     sync()
-    # timed region: exactly K passes.  In pass mode every `stride`-th pass also records HIP events around its three launches
+    # timed region: exactly K passes.  In pass mode 4-5 of the passes also record HIP events around their three launches
     # (on the launch stream, by the library itself): the per-launch durations of the roofline object come from the timed region.
     sample = sg.launch == "pass" and not use_graph
-    stride = max(1, args.steps // 32)
+    stride = max(1, args.steps // 4)   # 4-5 sampled passes: the four event records cost ~7 us per sampled pass
     if sample:
         sg.reserve_pass_events(args.steps // stride + 1)
         events = []
