@@ -2,16 +2,19 @@
 
 One process per GPU.  Every rank owns a contiguous band of rows of EACH sub-grid (southern cap, Southern Ocean,
 Mercator, bipolar cap): cost per row differs by ~100x between the lat-lon sub-grids and the caps, so cutting the
-stitched grid into contiguous slabs would not balance.  One pass (default pipeline, ``latlon="fused"``) is
+stitched grid into contiguous slabs would not balance.  One pass (default pipeline, ``latlon="fused"``, ``launch="pass"``) is
 
-  main stream     one launch for all lat-lon bands (Mercator, Southern Ocean, regular southern cap): x, y, dx, dy, area,
-                  angle_dx from the axis formulas, 48 B written per cell, nothing read
-  side streams    bipolar mesh + angle | bipolar quadrature | displaced-pole mesh + angle | displaced-pole quadrature
+  ogg_tripolar_pass_dev   three launches on the caller's stream: the quadrature tables; then ONE launch that carries the
+                          lat-lon row strips (x, y, dx, dy, area, angle_dx from the axis formulas: 48 B written per cell,
+                          nothing read), the bipolar mesh + angle and the bipolar quadrature strips side by side; then the
+                          literal fix-up of the guarded cells
+  displaced-pole cap      its own kernels (mesh, angle, quadrature), on one side stream next to the pass
 
 with no exchange between ranks: the caps are analytic in (i, j) and the lat-lon kernel needs only the axis formulas.
-``latlon="stencil"`` is the pipeline of BASELINE.json's north_star taken literally: tile x, y (K1); send the first x/y row of
-every band to the rank below (neighbour send/recv over RCCL, torch.distributed backend "nccl"); generic 2x3-stencil kernel
-(K2) that reads x, y back.  Both give the same bits.
+``launch="kernels"`` runs one launch per sub-grid and phase instead (the caps on side streams when ``overlap`` is set) and gives
+the same bits.  ``latlon="stencil"`` is the pipeline of BASELINE.json's north_star taken literally: tile x, y (K1); send the first
+x/y row of every band to the rank below (neighbour send/recv over RCCL, torch.distributed backend "nccl"); generic 2x3-stencil
+kernel (K2) that reads x, y back.  Same bits again.  ``metrics_error()`` is the one collective of the default pipeline.
 
 All six fields of every band stay in HBM (torch tensors); ``bands_to_host()`` copies them out and ``stitch()`` assembles the
 sub-grids on the host exactly as the reference does (OGG:1315-1365).
