@@ -8,13 +8,13 @@ extern "C" int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band
     if (int e = plan_latlon(n_bands, bands, ni1, lon0, lenlon, Re, metrics, p, points)) return e;
     if (p.n_bands == 0) return OGG_OK;
     const long gx = latlon_gx(ni1);
-    // Resident workgroups (each owns 512 columns and walks its row strips grid-stride): the write path saturates with 60-100 of
-    // them and MORE are slower (1/8 degree, 19.8 M points: 60 -> 4.6 TB/s, 96 -> 4.45, 512 -> 4.16, 2048 -> 4.0; 1/16 degree: best
-    // at 96-144); small launches are latency-bound and want a few hundred.
-    long max_wg = points >= 8000000 ? 96 : 240;
+    // Resident workgroups (each owns 512 columns and a contiguous block of row strips inside its XCD's eighth of the rows): the
+    // write path saturates with 150-250 of them (1/8 degree, 19.8 M points: 60 -> 5.1 TB/s, 240 -> 4.9-5.5, 1024 -> 4.3; 1/16
+    // degree: 240 -> 4.7 TB/s); without the per-XCD assignment the plateau was 4.3-4.6 TB/s.
+    long max_wg = 240;
     if (const char* e = getenv("OGG_FUSED_MAX_WG")) max_wg = atol(e);
     long gy = p.strip0[p.n_bands];
-    if (gx * gy > max_wg) gy = (max_wg + gx - 1) / gx;
+    if (gx * gy > max_wg) gy = latlon_round_gy(gx, (max_wg + gx - 1) / gx);
     dim3 grid((unsigned)gx, (unsigned)(gy < 1 ? 1 : gy));
     latlon_fused_kernel<<<grid, LF_TX, 0, ogg::as_stream(stream)>>>(p);
     OGG_LAUNCH_CHECK();

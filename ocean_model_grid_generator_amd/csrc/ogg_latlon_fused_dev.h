@@ -138,17 +138,31 @@ OGG_DEV void latlon_rows(const FusedParams& p, const ogg_latlon_band& b, const R
 
 constexpr int LF_COLS = 2 * LF_TX;  // columns per workgroup: every thread owns two adjacent columns
 inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
+// row groups in flight: rounded up so that gx * gy is a multiple of 8 (one equal share per XCD, see latlon_fused_body)
+inline long latlon_round_gy(long gx, long gy) {
+    const long g = gx % 8 == 0 ? 1 : (gx % 4 == 0 ? 2 : (gx % 2 == 0 ? 4 : 8));   // 8 / gcd(gx, 8)
+    return ((gy + g - 1) / g) * g;
+}
 
 // workgroup bx of the column tiles; it takes the row strips strip_lo + by, + gy, ... < strip_hi.  s_row: LF_ROWS + 1 entries.
-OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long bx, long by, long gy, long strip_lo, long strip_hi) {
+// b: index of this workgroup among the gx * gy lat-lon workgroups of the launch, in dispatch order.  Workgroups are handed to
+// the 8 XCDs round-robin, so workgroup b runs on XCD b % 8; the remap below gives every XCD a CONTIGUOUS eighth of the row
+// strips (all column tiles of those rows) and every workgroup a contiguous block of strips, instead of interleaving the XCDs
+// strip by strip: +15 % on the write plateau in scripts/microbench/write_patterns.hip (pattern b2).
+OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi) {
+    const long n_wg = gx * gy;
+    const long v = (n_wg % 8 == 0) ? (b % 8) * (n_wg / 8) + b / 8 : b;   // virtual index: XCD x owns [x n_wg/8, (x+1) n_wg/8)
+    const long bx = v % gx, by = v / gx;
     const int tid = threadIdx.x;
     const long i0 = (bx * LF_TX + tid) * 2;
     const long ni1 = p.ni1, ni = ni1 - 1;
     const ColScalars c0 = column_scalars(p, i0), c1 = column_scalars(p, i0 + 1);
     const bool full = i0 + 1 < ni;  // both columns exist and have a right neighbour
-    // Row strips of all bands are taken grid-stride: the launch caps the number of resident workgroups (an HBM-write-bound
-    // kernel needs only a few waves per SIMD) so that VALU-bound workgroups can share the CUs.
-    for (long strip = strip_lo + by; strip < strip_hi; strip += gy) {
+    // The launch caps the number of resident workgroups (an HBM-write-bound kernel needs only a few waves per SIMD) so that
+    // VALU-bound workgroups can share the CUs; each workgroup walks its block of row strips.
+    const long per = (strip_hi - strip_lo + gy - 1) / gy;
+    const long s_first = strip_lo + by * per, s_last = (s_first + per < strip_hi) ? s_first + per : strip_hi;
+    for (long strip = s_first; strip < s_last; ++strip) {
         int bi = 0;
         while (bi + 1 < p.n_bands && strip >= p.strip0[bi + 1]) ++bi;
         const ogg_latlon_band& b = p.band[bi];
@@ -187,7 +201,7 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long bx,
 
 __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
     __shared__ RowScalars s_row[LF_ROWS + 1];
-    latlon_fused_body(p, s_row, blockIdx.x, blockIdx.y, gridDim.y, 0, p.strip0[p.n_bands]);
+    latlon_fused_body(p, s_row, (long)blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, 0, p.strip0[p.n_bands]);
 }
 
 // Validates the bands and fills the kernel parameters; returns the number of points (0: nothing to do).

@@ -88,6 +88,29 @@ __global__ __launch_bounds__(256) void k_h(Six s, const double* __restrict__ tab
         }
     }
 }
+// b2: pattern b with an XCD-aware remap: workgroup b runs on XCD b % 8; give every XCD a contiguous eighth of the row strips
+__global__ __launch_bounds__(256) void k_b2(Six s, int rows_per_strip, int wg_per_xcd, int remap) {
+    const long n_strips = (ROWS + rows_per_strip - 1) / rows_per_strip;
+    const int b = blockIdx.x;                       // 12 column tiles x gy strips-in-flight
+    int v = b;
+    if (remap) v = (b % 8) * wg_per_xcd + b / 8;    // virtual id: XCD x owns ids [x * wg_per_xcd, (x+1) * wg_per_xcd)
+    const int total = 8 * wg_per_xcd;
+    const long tile = v % 12, lane_strip = v / 12, gy = total / 12;
+    const long i0 = (tile * 256 + threadIdx.x) * 2;
+    if (i0 + 1 >= NI1) return;
+    // strips of this virtual workgroup: contiguous block of the strip range when remapped, grid-stride otherwise
+    const long per = (n_strips + gy - 1) / gy;
+    for (long k = 0; k < per; ++k) {
+        const long st = remap ? lane_strip * per + k : lane_strip + k * gy;
+        if (st >= n_strips) break;
+        const long j0 = st * rows_per_strip, j1 = (j0 + rows_per_strip < ROWS) ? j0 + rows_per_strip : ROWS;
+        for (long j = j0; j < j1; ++j) {
+            dbl2 v2; v2.x = (double)j, v2.y = (double)i0;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) *reinterpret_cast<dbl2*>(s.f[f] + j * NI1 + i0) = v2;
+        }
+    }
+}
 template <class F> float timeit(F f) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int k = 0; k < 3; ++k) f();
@@ -102,6 +125,7 @@ int main() {
     const double gb6 = 6.0 * N * 8 / 1e9;
     { const long n2 = 3 * N; float ms = timeit([&] { k_a<<<(unsigned)((n2 + 255) / 256), 256>>>(big, n2); }); printf("a  one array contiguous             %7.3f ms %7.1f GB/s\n", ms, gb6 / ms * 1e3); }
     for (int g : {2, 3, 5, 8, 12, 24, 100}) { float ms = timeit([&] { k_b<<<dim3(12, g), 256>>>(s, 16); }); printf("b  6 arrays, 4 KB x rows, %4d WGs    %7.3f ms %7.1f GB/s\n", 12 * g, ms, gb6 / ms * 1e3); }
+    for (int wpx : {12, 24, 48, 96}) for (int rm : {0, 1}) { float ms = timeit([&] { k_b2<<<8 * wpx, 256>>>(s, 16, wpx, rm); }); printf("b2 6 arrays, 4 KB x rows, %4d WGs, XCD remap %d %7.3f ms %7.1f GB/s\n", 8 * wpx, rm, ms, gb6 / ms * 1e3); }
     for (long ch : {1024L, 4096L, 16384L}) { const long chunks = (N / 2 + ch - 1) / ch; float ms = timeit([&] { k_c<<<(unsigned)(chunks * 6), 256>>>(s, ch); }); printf("c  6 arrays, field WGs %6ld KB chunk %7.3f ms %7.1f GB/s\n", ch * 16 / 1024, ms, gb6 / ms * 1e3); }
     for (int g : {32, 64, 128, 256, 512, 1024}) { float ms = timeit([&] { k_d<<<g, 256>>>(s); }); printf("d  6 arrays, whole rows, %4d WGs      %7.3f ms %7.1f GB/s\n", g, ms, gb6 / ms * 1e3); }
     double* tab; hipMalloc(&tab, (NI1 + 16) * 8); hipMemset(tab, 0, (NI1 + 16) * 8);
