@@ -14,7 +14,7 @@ extern "C" int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band
     long max_wg = 240;
     if (const char* e = getenv("OGG_FUSED_MAX_WG")) max_wg = atol(e);
     long gy = p.strip0[p.n_bands];
-    if (gx * gy > max_wg) gy = latlon_round_gy(gx, (max_wg + gx - 1) / gx);
+    if (gx * gy > max_wg) gy = (max_wg + gx - 1) / gx;
     dim3 grid((unsigned)gx, (unsigned)(gy < 1 ? 1 : gy));
     latlon_fused_kernel<<<grid, LF_TX, 0, ogg::as_stream(stream)>>>(p);
     OGG_LAUNCH_CHECK();

@@ -138,11 +138,6 @@ OGG_DEV void latlon_rows(const FusedParams& p, const ogg_latlon_band& b, const R
 
 constexpr int LF_COLS = 2 * LF_TX;  // columns per workgroup: every thread owns two adjacent columns
 inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
-// row groups in flight: rounded up so that gx * gy is a multiple of 8 (one equal share per XCD, see latlon_fused_body)
-inline long latlon_round_gy(long gx, long gy) {
-    const long g = gx % 8 == 0 ? 1 : (gx % 4 == 0 ? 2 : (gx % 2 == 0 ? 4 : 8));   // 8 / gcd(gx, 8)
-    return ((gy + g - 1) / g) * g;
-}
 
 // workgroup bx of the column tiles; it takes the row strips strip_lo + by, + gy, ... < strip_hi.  s_row: LF_ROWS + 1 entries.
 // b: index of this workgroup among the gx * gy lat-lon workgroups of the launch, in dispatch order.  Workgroups are handed to
@@ -150,8 +145,8 @@ inline long latlon_round_gy(long gx, long gy) {
 // strips (all column tiles of those rows) and every workgroup a contiguous block of strips, instead of interleaving the XCDs
 // strip by strip: +15 % on the write plateau in scripts/microbench/write_patterns.hip (pattern b2).
 OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi) {
-    const long n_wg = gx * gy;
-    const long v = (n_wg % 8 == 0) ? (b % 8) * (n_wg / 8) + b / 8 : b;   // virtual index: XCD x owns [x n_wg/8, (x+1) n_wg/8)
+    const long n_wg = gx * gy, x = b % 8;
+    const long v = x * (n_wg / 8) + ((x < n_wg % 8) ? x : n_wg % 8) + b / 8;   // virtual index: the workgroups of XCD x are consecutive
     const long bx = v % gx, by = v / gx;
     const int tid = threadIdx.x;
     const long i0 = (bx * LF_TX + tid) * 2;

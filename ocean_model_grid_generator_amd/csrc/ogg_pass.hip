@@ -106,7 +106,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     const long points = (hi - lo) * ll.rows_per_block * ni1;
     long max_wg = alone ? 2048 : (points >= 4000000 ? env_long("OGG_PASS_LL_WG", 60) : env_long("OGG_PASS_LL_WG_SMALL", 120));
     long gy = hi - lo;
-    if (s.gx * gy > max_wg) gy = latlon_round_gy(s.gx, (max_wg + s.gx - 1) / s.gx);
+    if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
     s.gy = gy < 1 ? 1 : gy;
     s.n_wg = s.gx * s.gy;
     return s;
