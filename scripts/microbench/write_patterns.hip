@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_b2(Six s, int rows_per_strip, int wg_pe
     const long n_strips = (ROWS + rows_per_strip - 1) / rows_per_strip;
     const int b = blockIdx.x;                       // 12 column tiles x gy strips-in-flight
     int v = b;
-    if (remap == 1) v = (b % 8) * wg_per_xcd + b / 8;   // virtual id: XCD x owns ids [x * wg_per_xcd, (x+1) * wg_per_xcd)
+    if (remap == 1 || remap == 3) v = (b % 8) * wg_per_xcd + b / 8;   // virtual id: XCD x owns ids [x * wg_per_xcd, (x+1) * wg_per_xcd)
     // remap == 2: contiguous blocks of strips per workgroup, but no per-XCD grouping (v = b)
     const int total = 8 * wg_per_xcd;
     const long tile = v % 12, lane_strip = v / 12, gy = total / 12;
@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void k_b2(Six s, int rows_per_strip, int wg_pe
     if (i0 + 1 >= NI1) return;
     // strips of this virtual workgroup: contiguous block of the strip range when remapped, grid-stride otherwise
     const long per = (n_strips + gy - 1) / gy;
+    // remap == 3: XCD x owns a contiguous eighth of the strips; its row-lanes take them grid-stride (one compact window per XCD)
+    const long lanes_x = (gy + 7) / 8, x = lane_strip / lanes_x, l = lane_strip % lanes_x, per_x = (n_strips + 7) / 8;
     for (long k = 0; k < per; ++k) {
-        const long st = remap ? lane_strip * per + k : lane_strip + k * gy;
+        long st = remap ? lane_strip * per + k : lane_strip + k * gy;
+        if (remap == 3) { st = x * per_x + l + k * lanes_x; if (l + k * lanes_x >= per_x) break; }
         if (st >= n_strips) break;
         const long j0 = st * rows_per_strip, j1 = (j0 + rows_per_strip < ROWS) ? j0 + rows_per_strip : ROWS;
         for (long j = j0; j < j1; ++j) {
@@ -126,7 +129,7 @@ int main() {
     const double gb6 = 6.0 * N * 8 / 1e9;
     { const long n2 = 3 * N; float ms = timeit([&] { k_a<<<(unsigned)((n2 + 255) / 256), 256>>>(big, n2); }); printf("a  one array contiguous             %7.3f ms %7.1f GB/s\n", ms, gb6 / ms * 1e3); }
     for (int g : {2, 3, 5, 8, 12, 24, 100}) { float ms = timeit([&] { k_b<<<dim3(12, g), 256>>>(s, 16); }); printf("b  6 arrays, 4 KB x rows, %4d WGs    %7.3f ms %7.1f GB/s\n", 12 * g, ms, gb6 / ms * 1e3); }
-    for (int wpx : {12, 24, 48, 96}) for (int rm : {0, 1, 2}) { float ms = timeit([&] { k_b2<<<8 * wpx, 256>>>(s, 16, wpx, rm); }); printf("b2 6 arrays, 4 KB x rows, %4d WGs, XCD remap %d %7.3f ms %7.1f GB/s\n", 8 * wpx, rm, ms, gb6 / ms * 1e3); }
+    for (int wpx : {12, 24, 48, 96}) for (int rm : {0, 1, 2, 3}) { float ms = timeit([&] { k_b2<<<8 * wpx, 256>>>(s, 16, wpx, rm); }); printf("b2 6 arrays, 4 KB x rows, %4d WGs, XCD remap %d %7.3f ms %7.1f GB/s\n", 8 * wpx, rm, ms, gb6 / ms * 1e3); }
     for (long ch : {1024L, 4096L, 16384L}) { const long chunks = (N / 2 + ch - 1) / ch; float ms = timeit([&] { k_c<<<(unsigned)(chunks * 6), 256>>>(s, ch); }); printf("c  6 arrays, field WGs %6ld KB chunk %7.3f ms %7.1f GB/s\n", ch * 16 / 1024, ms, gb6 / ms * 1e3); }
     for (int g : {32, 64, 128, 256, 512, 1024}) { float ms = timeit([&] { k_d<<<g, 256>>>(s); }); printf("d  6 arrays, whole rows, %4d WGs      %7.3f ms %7.1f GB/s\n", g, ms, gb6 / ms * 1e3); }
     double* tab; hipMalloc(&tab, (NI1 + 16) * 8); hipMemset(tab, 0, (NI1 + 16) * 8);
