@@ -45,10 +45,11 @@ constexpr int TILE_ROWS = 16;
 __global__ __launch_bounds__(TILE_TX) void tile_latlon_kernel(long nrows, long ni1, const double* __restrict__ lat1d,
                                                               const double* __restrict__ lon1d, double* __restrict__ x,
                                                               double* __restrict__ y) {
-    const long i = (long)blockIdx.x * TILE_TX + threadIdx.x;
+    const long v = xcd_contiguous((long)blockIdx.y * gridDim.x + blockIdx.x, (long)gridDim.x * gridDim.y);  // one row range per XCD
+    const long i = (v % gridDim.x) * TILE_TX + threadIdx.x;
     if (i >= ni1) return;
     const double lon = lon1d[i];
-    const long j0 = (long)blockIdx.y * TILE_ROWS;
+    const long j0 = (v / gridDim.x) * TILE_ROWS;
     const long j1 = (j0 + TILE_ROWS < nrows) ? j0 + TILE_ROWS : nrows;
     for (long j = j0; j < j1; ++j) {
         const double lat = lat1d[j];  // wave-uniform: scalar load

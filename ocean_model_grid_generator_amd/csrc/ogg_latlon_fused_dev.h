@@ -145,8 +145,7 @@ inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
 // strips (all column tiles of those rows) and every workgroup a contiguous block of strips, instead of interleaving the XCDs
 // strip by strip: +15 % on the write plateau in scripts/microbench/write_patterns.hip (pattern b2).
 OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi) {
-    const long n_wg = gx * gy, x = b % 8;
-    const long v = x * (n_wg / 8) + ((x < n_wg % 8) ? x : n_wg % 8) + b / 8;   // virtual index: the workgroups of XCD x are consecutive
+    const long v = xcd_contiguous(b, gx * gy);   // virtual index: the workgroups of XCD x are consecutive
     const long bx = v % gx, by = v / gx;
     const int tid = threadIdx.x;
     const long i0 = (bx * LF_TX + tid) * 2;

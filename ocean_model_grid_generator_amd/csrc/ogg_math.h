@@ -139,6 +139,15 @@ OGG_DEV double wave_next(double x) {  // lane l gets the value of lane l+1
 }
 OGG_DEV int wave_next(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
 
+// Workgroups are handed to the 8 XCDs of the chip round-robin: workgroup b (linear index in dispatch order) runs on XCD
+// b % 8.  xcd_contiguous renumbers the n workgroups of a launch so that the workgroups of one XCD get CONSECUTIVE virtual
+// indices: with rows as the slow index of the virtual numbering every XCD then writes a contiguous eighth of the rows, which
+// the HBM write path rewards (+15 % on strided multi-array writes, scripts/microbench/write_patterns.hip pattern b2).
+OGG_DEV long xcd_contiguous(long b, long n) {
+    const long x = b % 8, r = n % 8;
+    return x * (n / 8) + ((x < r) ? x : r) + b / 8;
+}
+
 // Gauss-Lobatto node weights of OGG:191-204, computed on the host in IEEE double and passed by value.
 struct QuadNodes {
     double a[5];

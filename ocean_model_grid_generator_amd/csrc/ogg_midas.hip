@@ -98,13 +98,15 @@ OGG_DEV double angle_of(const RowVals& v, long i, long ni1) {
 
 template <bool METRICS, bool AREAFIX>
 __global__ __launch_bounds__(MIDAS_TX) void midas_angle_kernel(MidasParams p) {
-    const long i = (long)blockIdx.x * MIDAS_TX + threadIdx.x;
+    const long v = xcd_contiguous((long)blockIdx.y * gridDim.x + blockIdx.x, (long)gridDim.x * gridDim.y);  // rows slow: one row range per XCD
+    const long vbx = v % gridDim.x, vby = v / gridDim.x;
+    const long i = vbx * MIDAS_TX + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const long ni1 = p.ni1;
     const long ni = ni1 - 1;
     const bool active = i < ni1;
     const bool has_r = i + 1 < ni1;
-    const long js = (long)blockIdx.y * p.rows_per_block;
+    const long js = vby * p.rows_per_block;
     const long je = (js + p.rows_per_block < p.n_pt_rows) ? js + p.rows_per_block : p.n_pt_rows;
 
     RowVals cur = load_row(p.x, p.y, js, ni1, i, lane);
