@@ -30,6 +30,8 @@ extern "C" {
 
 const char* ogg_last_error(void);
 const char* ogg_version(void);
+/* sizeof(ogg_latlon_band) for which = 0, sizeof(ogg_bipolar_band) for which = 1 (-1 otherwise): lets a binding verify its layout */
+long ogg_abi_sizeof(int which);
 int ogg_device_count(int* count);
 int ogg_set_device(int device);
 int ogg_device_name(char* buf, int buflen);

@@ -115,7 +115,8 @@ SIGNATURES = {
     "ogg_stream_synchronize": [c_void_p],
 }
 STRING_GETTERS = ("ogg_last_error", "ogg_version")
-LONG_GETTERS = {"ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long],
+LONG_GETTERS = {"ogg_abi_sizeof": [c_int],
+                "ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long],
                 "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long]}
 
 _lib = None

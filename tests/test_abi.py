@@ -41,6 +41,24 @@ def test_ctypes_table_covers_the_header():
     assert lib.ogg_version().startswith(b"ogg_hip")
 
 
+def test_descriptor_structs_have_the_c_layout():
+    """The ctypes mirrors of the two descriptor structs must have the size the compiler gives them (a silent mismatch would
+    shift every pointer), and the pass validates its arguments before any device work."""
+    from ocean_model_grid_generator_amd import _lib
+    lib = _lib.load()
+    assert lib.ogg_abi_sizeof(0) == ctypes.sizeof(_lib.LatlonBand)
+    assert lib.ogg_abi_sizeof(1) == ctypes.sizeof(_lib.BipolarBand)
+    assert lib.ogg_abi_sizeof(2) == -1
+    bands = (_lib.LatlonBand * 5)()
+    rc = lib.ogg_tripolar_pass_dev(5, bands, 1441, -300.0, 360.0, 6371e3, 1, None, None)     # more than 4 lat-lon bands
+    assert rc == _lib.OGG_EARG and b"at most 4 bands" in lib.ogg_last_error()
+    cap = _lib.BipolarBand()
+    cap.Ni, cap.Nj, cap.n_pt_rows, cap.order = 1440, 10, 4, 9
+    cap.x = cap.y = cap.angle = cap.dx = cap.dy = cap.area = 8     # never dereferenced: validation comes first
+    rc = lib.ogg_tripolar_pass_dev(0, bands, 1441, -300.0, 360.0, 6371e3, 1, ctypes.byref(cap), None)
+    assert rc == _lib.OGG_EORDER and lib.ogg_last_error() == b"Uncoded order"
+
+
 def test_argument_errors_use_reference_texts():
     """Validation happens before any device work, so these run without a GPU."""
     from ocean_model_grid_generator_amd import _lib
