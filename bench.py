@@ -70,8 +70,10 @@ def band_points(plan, rank, world, sg_mod):
     return pts
 
 
-def cpu_baseline(flags, sample_div):
-    """Oracle timed on the southernmost 1/sample_div of the rows of every sub-grid (1 thread, like the reference)."""
+def cpu_baseline(flags, sample_div, per_cell_loop=False):
+    """Oracle timed on the southernmost 1/sample_div of the rows of every sub-grid (1 thread, like the reference).
+    ``per_cell_loop``: the quadratures average cell by cell in Python like the reference (OGG:176-187, 585-599) instead of
+    vectorised over the chunk -- the "reference-shaped" row of SURVEY 8(d)."""
     from oracle import ogg_oracle as orc
 
     r = flags["inverse_resolution"]
@@ -101,7 +103,7 @@ def cpu_baseline(flags, sample_div):
     rp = np.tan(0.5 * (90 - lat0_bp) * orc.PI_180)
     lams, phis, _, _ = orc.bipolar_projection(np.tile(lon_g, (n + 1, 1)), np.tile(latg.reshape(-1, 1), (1, Ni + 1)), -300.0, rp)
     orc.angle_x(lams, phis)
-    orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0_bp, -300.0, rp, rows_per_chunk=16, j_last=n)
+    orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0_bp, -300.0, rp, rows_per_chunk=16, j_last=n, per_cell_loop=per_cell_loop)
     cells += n * Ni
     latUp = phi_M[0]
     so_axis = -78.0 + np.arange(int(r * 55) + 1) * (latUp + 78.0) / float(int(r * 55))
@@ -116,7 +118,8 @@ def cpu_baseline(flags, sample_div):
         n = max((Njs - jm) // sample_div, 1)
         x, y, _, _ = orc.displacedPoleCap_mesh(np.arange(Ni + 1), np.arange(jm, jm + n + 1), Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp)
         orc.angle_x(x, y)
-        orc.displacedPoleCap_metrics_quad(4, Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp, rows_per_chunk=8, j_first=jm, j_last=jm + n)
+        orc.displacedPoleCap_metrics_quad(4, Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp, rows_per_chunk=8, j_first=jm, j_last=jm + n,
+                                          per_cell_loop=per_cell_loop)
         cells += n * Ni
     else:
         Njs = int((-78.0 + 90.0) / (1.0 / r / 2))
@@ -360,6 +363,13 @@ def main():
                                    "sample": "numpy oracle on the southernmost 1/%d of the rows of every sub-grid of the same "
                                              "workload: %d cells in %.1f s" % (args.cpu_sample_div, cells, cdt),
                                    "host_cpus": os.cpu_count()}
+            # the same span with the reference's per-cell Python loops in the quadratures, on a smaller sample (a few seconds)
+            rs_div = max(64, args.cpu_sample_div)
+            cells2, cdt2 = cpu_baseline(flags, rs_div, per_cell_loop=True)
+            out["cpu_baseline_reference_shaped"] = {
+                "value": cells2 / cdt2, "unit": "cells/s", "cores": 1, "kind": "port",
+                "sample": "as cpu_baseline but the quadratures average cell by cell in Python like the reference (OGG:176-187, 585-599); "
+                          "southernmost 1/%d of the rows: %d cells in %.1f s" % (rs_div, cells2, cdt2)}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -367,8 +367,24 @@ def bipolar_cap_ij_array(i, j, Ni, Nj_ncap, lat0_bp, lon_bp, rp):
     return h_i_inv, h_j_inv
 
 
+def _quad_chunk(dx_r, dy_r, dxq, dyq, daq, c0, c1, per_cell_loop):
+    """Lobatto means of one chunk of cell rows.  ``per_cell_loop``: one Python-level call per cell, as the reference does it
+    (OGG:176-187 / 585-599) -- the same values, only slower; bench.py uses it for the "reference-shaped" CPU row."""
+    dxdy_r = dx_r * dy_r
+    if not per_cell_loop:
+        daq[c0:c1] = quad_average_2d(dxdy_r.transpose(0, 2, 1, 3))
+        dxq[c0:c1] = quad_average(dx_r[:, 0, :, :])
+        dyq[c0:c1] = quad_average(dy_r[:, :, :, 0].transpose(0, 2, 1))
+        return
+    for j in range(c1 - c0):
+        for i in range(dx_r.shape[2]):
+            daq[c0 + j, i] = quad_average_2d(dxdy_r[j, :, i, :])
+            dxq[c0 + j, i] = quad_average(dx_r[j, 0, i, :])
+            dyq[c0 + j, i] = quad_average(dy_r[j, :, i, 0])
+
+
 def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=RE_DEFAULT, rows_per_chunk=64, j_first=0,
-                                  j_last=None):
+                                  j_last=None, per_cell_loop=False):
     """dx (ny+1,nx), dy (ny,nx+1), area (ny,nx) by Lobatto quadrature of h.  OGG:136-188.
     Evaluated in chunks of cell rows; the per-element arithmetic and the summation order are the
     reference's (the reference's own chunking, OGG:161-172, is likewise semantically irrelevant).  ``j_first`` /
@@ -388,10 +404,7 @@ def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=RE_DEFA
         dx, dy = bipolar_cap_ij_array(i1d, j1d[c0 * order:c1 * order], nx, ny, lat0_bp, lon_bp, rp)
         dx_r = dx.reshape(c1 - c0, order, nx + 1, order)
         dy_r = dy.reshape(c1 - c0, order, nx + 1, order)
-        dxdy_r = dx_r * dy_r
-        daq[c0:c1] = quad_average_2d(dxdy_r.transpose(0, 2, 1, 3))
-        dxq[c0:c1] = quad_average(dx_r[:, 0, :, :])
-        dyq[c0:c1] = quad_average(dy_r[:, :, :, 0].transpose(0, 2, 1))
+        _quad_chunk(dx_r, dy_r, dxq, dyq, daq, c0, c1, per_cell_loop)
     return dxq[:, :-1] * Re, dyq[:-1, :] * Re, daq[:-1, :-1] * Re * Re
 
 
@@ -481,7 +494,7 @@ def numerical_hj(j, i, nx, ny, lon0, lat0, lon_dp, r_dp, eps, order=6):
 
 
 def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=RE_DEFAULT, rows_per_chunk=32,
-                                  j_first=0, j_last=None):
+                                  j_first=0, j_last=None, per_cell_loop=False):
     """dx (ny+1,nx), dy (ny,nx+1), area (ny,nx) by quadrature of finite-difference h.  OGG:565-601.
     Cell rows are independent (the unwrap scan runs along i inside a lattice row), so the evaluation is
     chunked by cell rows; ``j_first`` skips cell rows < j_first (left as zeros) -- the rows main() discards
@@ -500,10 +513,7 @@ def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=RE
         dy = numerical_hj(jj, i1d, nx, ny, lon0, lat0, lon_dp, r_dp, eps=1e-3, order=order)
         dx_r = dx.reshape(c1 - c0, order, nx + 1, order)
         dy_r = dy.reshape(c1 - c0, order, nx + 1, order)
-        dxdy_r = dx_r * dy_r
-        daq[c0:c1] = quad_average_2d(dxdy_r.transpose(0, 2, 1, 3))
-        dxq[c0:c1] = quad_average(dx_r[:, 0, :, :])
-        dyq[c0:c1] = quad_average(dy_r[:, :, :, 0].transpose(0, 2, 1))
+        _quad_chunk(dx_r, dy_r, dxq, dyq, daq, c0, c1, per_cell_loop)
     return dxq[:, :-1] * Re, dyq[:-1, :] * Re, daq[:-1, :-1] * Re * Re
 
 
