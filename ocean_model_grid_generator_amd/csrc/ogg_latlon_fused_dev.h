@@ -26,7 +26,7 @@ namespace {
 using namespace ogg;
 
 constexpr int LF_TX = 256;
-constexpr int LF_ROWS = 32;  // maximum rows per workgroup (LDS row table); small bands use fewer so that the grid stays >= ~2000 workgroups
+constexpr int LF_ROWS = 32;  // maximum rows per strip (LDS row table); small bands use fewer (>= 8) so that there are enough strips
 constexpr int LF_MAX_BANDS = 4;
 
 struct FusedParams {
@@ -221,7 +221,7 @@ inline int plan_latlon(int n_bands, const ogg_latlon_band* bands, long ni1, doub
     if (p.n_bands == 0) return OGG_OK;
     const long gx = latlon_gx(ni1);
     long rpb = (total_rows * gx + 2047) / 2048;  // aim at >= 2048 row strips x column tiles
-    rpb = rpb < 4 ? 4 : (rpb > LF_ROWS ? LF_ROWS : rpb);
+    rpb = rpb < 8 ? 8 : (rpb > LF_ROWS ? LF_ROWS : rpb);   // >= 8 rows per strip: the per-strip set-up (row scalars, two barriers) is worth ~2 rows
     p.strip0[0] = 0;
     for (int k = 0; k < p.n_bands; ++k) p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
     p.ni1 = ni1, p.lon0 = lon0, p.lenlon = lenlon, p.Ni = (double)(ni1 - 1);
