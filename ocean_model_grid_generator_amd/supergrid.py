@@ -118,8 +118,10 @@ class SupergridPlan(object):
             lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
             guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
             fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
-            w_fix, w_guard = (float(v) for v in os.environ.get("OGG_BP_ROW_COST", "2.0,1.3").split(","))
+            w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "2.0,1.3,0").split(",")]
+            w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
             bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
+            bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
         # Southern Ocean (OGG:1080-1103)
         lat0_SO = -78.0
         lenlat_SO = latUp_SO - lat0_SO
