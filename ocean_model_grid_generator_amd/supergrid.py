@@ -107,18 +107,19 @@ class SupergridPlan(object):
             Nj_ncap -= 1
         bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=lat0_bp, lon_bp=self.lon0,
                          rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
-        # Row cost for the band split of the cap.  The quadrature guards its algebraic per-point form near the two pole points
-        # (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K)) carry the guard (1.3x a
-        # plain row), and those above acos(1/sqrt(K)) also contain the cells the literal fix-up re-evaluates (2.0x) -- weights
-        # that equalise the measured per-rank times of the fused pass at 1/8 degree over 2, 4 and 8 ranks
-        # (scripts/rank_sweep.py; OGG_BP_ROW_COST="fix,guard" overrides them).
+        # Row cost for the band split of the cap, in units of a plain cell row.  The quadrature guards its algebraic per-point form
+        # near the two pole points (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K))
+        # carry the guard (1.3x a plain row), and the band that holds the last row also runs the tail launch (literal fix-up of the
+        # guarded cells + the j = ny row), a fixed cost worth ~30 plain rows whatever the resolution.  These weights equalise the
+        # measured per-rank times of the fused pass at 1/8 and 1/16 degree over 2, 4 and 8 ranks (scripts/rank_sweep.py;
+        # OGG_BP_ROW_COST="fix,guard,lump" overrides them: weight of rows with fix-up cells, of guarded rows, lump on the last row).
         import os
         K = float(os.environ.get("OGG_BP_GUARD_K", "4000"))
         if K > 4.0:
             lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
             guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
             fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
-            w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "2.0,1.3,0").split(",")]
+            w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,30").split(",")]
             w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
             bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
             bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
