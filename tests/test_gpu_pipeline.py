@@ -307,3 +307,44 @@ def test_full_size_properties_r16_on_device(sg, world, rank):
         ys = {s.name: (float(g.buf[s.name]["y"][0, q]), float(g.buf[s.name]["y"][g.buf[s.name]["n"] - 1, q])) for s in plan.subs}
         assert ys["SC"][0] == -90.0 and ys["BP"][1] == 90.0
         assert ys["SC"][1] == ys["SO"][0] and ys["SO"][1] == ys["Merc"][0] and ys["Merc"][1] == ys["BP"][0]
+
+
+def test_full_size_r8_pass_vs_oracle(sg):
+    """The headline workload (1/8 degree, 25.3 M cells) through the fused pass against the numpy oracle, every field, every
+    element.  Bounds: test_gpu_parity.py's (module docstring there)."""
+    import torch
+    from test_gpu_parity import record
+    plan = sg.SupergridPlan(8.0)
+    g = sg.Supergrid(plan, device="cuda:0")
+    assert g.launch == "pass"
+    g.step()
+    torch.cuda.synchronize()
+    got = sg.stitch(plan, [g.bands_to_host()])
+    del g
+    want = orc.make_supergrid(8.0, skip_doughnut_rows=True)
+    rep = {}
+    for f in FIELDS:
+        assert got[f].shape == want[f].shape, f
+    d = np.abs(got["y"] - want["y"])
+    rep["y_max"] = float(d.max())
+    rep["y_max_excl_bp_poles"] = float(np.sort(d.ravel())[-5])          # the two pole points (and their duplicate columns)
+    assert rep["y_max_excl_bp_poles"] < 1e-12 and rep["y_max"] < 1e-6
+    d = np.abs(got["x"] - want["x"])
+    rep["x_max"] = float(d.max())
+    rep["x_frac_gt_1e12"] = float(np.mean(d > 1e-12))
+    assert rep["x_max"] < 2e-11 and rep["x_frac_gt_1e12"] < 1e-5                # next to the cap's symmetry meridians only
+    # dx, dy of the lat-lon sub-grids are differences of coordinates that themselves differ by ~1e-14 degrees (ocml vs the host
+    # libm in atan(sinh)): 1e-14 deg x 111 km/deg = 1e-9 m on a 7 km cell; area likewise (one ulp of sin moves it by 3e-5 m^2)
+    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (1e-3, 5e-12))):
+        d = np.abs(got[f] - want[f])
+        rep[f + "_max_abs"] = float(d.max())
+        rep[f + "_max_rel"] = float((d / np.maximum(np.abs(want[f]), 1e-300))[want[f] != 0].max())
+    record("full_r8_pass_vs_oracle", **rep)
+    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (1e-3, 5e-12))):
+        assert np.all(np.abs(got[f] - want[f]) <= a + r * np.abs(want[f])), (f, rep)
+    d = np.abs(got["angle_dx"] - want["angle_dx"])
+    d = np.minimum(d, np.abs(d - 360.0))
+    rep["angle_p999"] = float(np.quantile(d, 0.999))
+    rep["angle_frac_gt_1e9"] = float(np.mean(d > 1e-9))
+    assert rep["angle_p999"] < 1e-10 and rep["angle_frac_gt_1e9"] < 1e-5
+    record("full_r8_pass_vs_oracle", **rep)
