@@ -348,3 +348,35 @@ def test_full_size_r8_pass_vs_oracle(sg):
     rep["angle_frac_gt_1e9"] = float(np.mean(d > 1e-9))
     assert rep["angle_p999"] < 1e-10 and rep["angle_frac_gt_1e9"] < 1e-5
     record("full_r8_pass_vs_oracle", **rep)
+
+
+def test_full_size_r8_latdp_pass_vs_oracle(sg):
+    """BASELINE config 4 (1/8 degree with the displaced south pole, --lat_dp -85.85) at full size against the oracle (the
+    oracle needs ~40 s for the cap's finite-difference quadrature)."""
+    import torch
+    from test_gpu_parity import record
+    flags = dict(lon_dp=80.0, lat_dp=-85.85)
+    plan = sg.SupergridPlan(8.0, **flags)
+    g = sg.Supergrid(plan, device="cuda:0")
+    g.step()
+    torch.cuda.synchronize()
+    got = sg.stitch(plan, [g.bands_to_host()])
+    del g
+    want = orc.make_supergrid(8.0, skip_doughnut_rows=True, **flags)
+    nsc = plan.subs[0].nj1 - 1      # cell rows of the displaced-pole cap: finite-difference metrics, 5e-7 relative (test_gpu_parity)
+    assert plan.subs[0].kind == "dpole"
+    rep = {}
+    for f in FIELDS:
+        assert got[f].shape == want[f].shape, f
+    rep["y_max"] = float(np.abs(got["y"] - want["y"]).max())
+    d = np.abs(got["x"] - want["x"])
+    rep["x_max"] = float(np.minimum(d, np.abs(d - 360.0)).max())
+    assert rep["y_max"] < 1e-12 and rep["x_max"] < 2e-11
+    for f in ("dx", "dy", "area"):
+        d = np.abs(got[f] - want[f])
+        rel = d / np.maximum(np.abs(want[f]), 1e-300)
+        rep[f + "_cap_max_rel"] = float(rel[:nsc][want[f][:nsc] != 0].max())
+        rep[f + "_rest_max_rel"] = float(rel[nsc:][want[f][nsc:] != 0].max())
+    record("full_r8_latdp_pass_vs_oracle", **rep)
+    for f in ("dx", "dy", "area"):
+        assert rep[f + "_cap_max_rel"] < 5e-7 and rep[f + "_rest_max_rel"] < 5e-12, (f, rep)
