@@ -216,9 +216,20 @@ int ogg_haversine(long n, const double* lam0, const double* phi0, const double* 
 int ogg_haversine_dev(long n, const double* lam0, const double* phi0, const double* lam1, const double* phi1, double* out,
                       void* stream);
 
-/* generate_displaced_pole_grid (OGG:509-518), rows j0..j0+nrows-1 of (Nj+1) x (Ni+1). */
+/* generate_displaced_pole_grid (OGG:509-518), rows j0..j0+nrows-1 of (Nj+1) x (Ni+1): projection, the sequential unwrap of
+ * monotonic_bounding (a look-back scan over the column strips of a row) and, when angle_dx != NULL, angle_x (OGG:719-729) of
+ * the same rows (nrows x (Ni+1)) without reading the mesh back -- one launch.  The _ws form takes a caller-provided device
+ * workspace (>= ogg_displaced_pole_grid_workspace_bytes; its first two 32-bit words are the work counter and an error flag,
+ * see ogg_workspace_error_flag_dev) and allocates nothing; the plain form uses the stream-ordered allocator. */
 int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0,
                                 long nrows, double* x, double* y, void* stream);
+long ogg_displaced_pole_grid_workspace_bytes(long Ni, long nrows);
+int ogg_displaced_pole_grid_angle_ws_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0,
+                                         long nrows, double* x, double* y, double* angle_dx, void* workspace,
+                                         long workspace_bytes, void* stream);
+/* Error flag of a workspace used by a displaced-pole call (*flag != 0: a look-back wait gave up, the results of that call are
+ * invalid; never observed, the spin is bounded so that a grid always drains).  Synchronises the stream. */
+int ogg_workspace_error_flag_dev(const void* workspace, int* flag, void* stream);
 
 /* numerical_hi / numerical_hj (OGG:535-562; great_arc_distance OGG:522-532) on the lattice j[n_j] x i[n_i].
  * fd_order in {2,4,6}.  h_i, h_j: n_j x n_i (either may be NULL). */
@@ -231,18 +242,33 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
 
 /* displacedPoleCap_metrics_quad (OGG:565-601): quadrature order (2..5) is also the finite-difference order, as in
  * the reference (OGG:583-584), so only orders 2 and 4 are valid.  Band form as for the bipolar cap; cell rows
- * below j0 are simply not evaluated (main() discards the doughnut rows, OGG:1177-1186). */
+ * below j0 are simply not evaluated (main() discards the doughnut rows, OGG:1177-1186).
+ * arc_form selects how the great-arc distance between two probes of the finite-difference stencil is taken:
+ *   OGG_DP_ARC_LITERAL  the reference's arithmetic (haversine of the projected, unwrapped longitudes and latitudes,
+ *                       OGG:522-532); the default of every entry point without an arc_form argument;
+ *   OGG_DP_ARC_CHORD    same stencil, distance from the gnomonic images of the probes (no atan2 / unwrap): ~7x less arithmetic,
+ *                       ~1.6e-9 relative from the reference's value (the reference's own rounding error there is ~2e-9), against
+ *                       ~1e-10 for the literal form.  Opt-in only. */
+#define OGG_DP_ARC_LITERAL 0
+#define OGG_DP_ARC_CHORD 1
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                         double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
                                         double* dxq, double* dyq, double* daq, void* stream);
-/* Same with a caller-provided workspace for the lattice values of h_i, h_j (at least
- * ogg_displaced_pole_quad_workspace_bytes(order, nx, n_cell_rows) bytes): no allocation inside the call. */
+/* Same with a caller-provided workspace for the row / column tables and the look-back words (at least
+ * ogg_displaced_pole_quad_workspace_bytes(order, nx, n_cell_rows) bytes; a few MB -- the lattice itself is never stored): no
+ * allocation inside the call.  One call at a time per workspace. */
 long ogg_displaced_pole_quad_workspace_bytes(int order, long nx, long n_cell_rows);
 int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                            double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
                                            double* dyq, double* daq, void* workspace, long workspace_bytes, void* stream);
+int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx, long ny, double lon0, double lat0,
+                                                double lon_dp, double r_dp, double Re, long j0, long n_dx_rows,
+                                                long n_cell_rows, double* dxq, double* dyq, double* daq, void* workspace,
+                                                long workspace_bytes, void* stream);
 int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
                                     double Re, double* dxq, double* dyq, double* daq);
+int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                         double r_dp, double Re, double* dxq, double* dyq, double* daq);
 
 /* ------------------------------------------------------------------------------------------------------
  * Device utilities used by the band-sharded pipeline (bench / multi-GPU)

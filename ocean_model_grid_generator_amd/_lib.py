@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libogg_hip.so")
 
 OGG_OK, OGG_EORDER, OGG_ESHAPE, OGG_EHIP, OGG_ENOMEM, OGG_EARG = 0, 1, 2, 3, 4, 5
+DP_ARC_LITERAL, DP_ARC_CHORD = 0, 1   # OGG_DP_ARC_* of include/ogg_hip.h
 
 c_long, c_int, c_double, c_void_p, c_longlong = ctypes.c_long, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_longlong
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -81,6 +82,13 @@ SIGNATURES = {
                                                c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ogg_displaced_pole_metrics_quad": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_void_p,
                                         c_void_p, c_void_p],
+    "ogg_displaced_pole_metrics_quad_form": [c_int, c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_void_p,
+                                             c_void_p, c_void_p],
+    "ogg_displaced_pole_metrics_quad_form_ws_dev": [c_int, c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double,
+                                                    c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ogg_displaced_pole_grid_angle_ws_dev": [c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ogg_workspace_error_flag_dev": [c_void_p, ctypes.POINTER(c_int), c_void_p],
     "ogg_y_mercator": [c_long, c_long, c_void_p, c_void_p],
     "ogg_y_mercator_dev": [c_long, c_long, c_void_p, c_void_p, c_void_p],
     "ogg_affine_index": [c_long, c_void_p, c_double, c_double, c_double, c_void_p],
@@ -117,7 +125,8 @@ SIGNATURES = {
 STRING_GETTERS = ("ogg_last_error", "ogg_version")
 LONG_GETTERS = {"ogg_abi_sizeof": [c_int],
                 "ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long],
-                "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long]}
+                "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long],
+                "ogg_displaced_pole_grid_workspace_bytes": [c_long, c_long]}
 
 _lib = None
 

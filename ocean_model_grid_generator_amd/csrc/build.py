@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ogg_api.hip", "ogg_axes.hip", "ogg_midas.hip", "ogg_bipolar.hip", "ogg_dpole.hip", "ogg_elementwise.hip", "ogg_latlon_fused.hip", "ogg_pass.hip", "ogg_reduce.hip"]
-HEADERS = ["ogg_common.h", "ogg_math.h", "ogg_bipolar_dev.h", "ogg_latlon_fused_dev.h", "../../include/ogg_hip.h"]
+HEADERS = ["ogg_common.h", "ogg_math.h", "ogg_bipolar_dev.h", "ogg_dpole_dev.h", "ogg_latlon_fused_dev.h", "../../include/ogg_hip.h"]
 LIB = os.path.join(HERE, "libogg_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function"]

@@ -289,20 +289,32 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
     return OGG_OK;
 }
 
-int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp, double Re,
-                                    double* dxq, double* dyq, double* daq) {
+int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                         double Re, double* dxq, double* dyq, double* daq) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
     OGG_REQUIRE(nx > 0 && ny > 0 && dxq && dyq && daq, OGG_EARG, "ogg_displaced_pole_metrics_quad: bad argument");
     DevScratch s;
-    double *d_dx, *d_dy, *d_da;
+    double *d_dx, *d_dy, *d_da, *d_ws;
+    const long ws_bytes = ogg_displaced_pole_quad_workspace_bytes(order, nx, ny);
     OGG_TRY(s.alloc(&d_dx, (ny + 1) * nx));
     OGG_TRY(s.alloc(&d_dy, ny * (nx + 1)));
     OGG_TRY(s.alloc(&d_da, ny * nx));
-    OGG_TRY(ogg_displaced_pole_metrics_quad_dev(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, 0, ny + 1, ny, d_dx, d_dy, d_da, nullptr));
+    OGG_TRY(s.alloc(&d_ws, (ws_bytes + 7) / 8));
+    OGG_TRY(ogg_displaced_pole_metrics_quad_form_ws_dev(arc_form, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, 0, ny + 1, ny, d_dx, d_dy,
+                                                        d_da, d_ws, ws_bytes, nullptr));
     OGG_TRY(download(dxq, d_dx, (ny + 1) * nx));
     OGG_TRY(download(dyq, d_dy, ny * (nx + 1)));
-    return download(daq, d_da, ny * nx);
+    OGG_TRY(download(daq, d_da, ny * nx));
+    int flag = 0;
+    OGG_TRY(ogg_workspace_error_flag_dev(d_ws, &flag, nullptr));
+    OGG_REQUIRE(flag == 0, OGG_EHIP, "ogg_displaced_pole_metrics_quad: a look-back wait timed out (flag %d)", flag);
+    return OGG_OK;
+}
+
+int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp, double Re,
+                                    double* dxq, double* dyq, double* daq) {
+    return ogg_displaced_pole_metrics_quad_form(OGG_DP_ARC_LITERAL, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, dxq, dyq, daq);
 }
 
 // ---- small element-wise entry points -----------------------------------------------------------------------

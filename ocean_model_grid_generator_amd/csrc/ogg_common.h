@@ -13,6 +13,30 @@ int set_error(int code, const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Scratch from the stream-ordered allocator (no host synchronisation), returned to it on EVERY exit path of the call.
+class AsyncScratch {
+   public:
+    explicit AsyncScratch(hipStream_t s) : s_(s) {}
+    AsyncScratch(const AsyncScratch&) = delete;
+    AsyncScratch& operator=(const AsyncScratch&) = delete;
+    ~AsyncScratch() {
+        if (p_) (void)hipFreeAsync(p_, s_);
+    }
+    int alloc(void** out, size_t bytes) {
+        hipError_t e = hipMallocAsync(&p_, bytes ? bytes : 1, s_);
+        if (e != hipSuccess) {
+            p_ = nullptr;
+            return set_error(e == hipErrorOutOfMemory ? OGG_ENOMEM : OGG_EHIP, "hipMallocAsync(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        }
+        *out = p_;
+        return OGG_OK;
+    }
+
+   private:
+    void* p_ = nullptr;
+    hipStream_t s_;
+};
+
 }  // namespace ogg
 
 #define OGG_HIP_CHECK(expr)                                                                              \

@@ -1,27 +1,19 @@
-// K5 / K6: displaced-pole Southern cap.
+// K5 / K6: displaced-pole Southern cap -- kernels and entry points.
 //   displacedPoleCap_projection / _mesh      OGG:447-506   (generate_displaced_pole_grid OGG:509-518)
 //   monotonic_bounding                       OGG:470-475
 //   great_arc_distance, numerical_hi/hj      OGG:522-562
 //   displacedPoleCap_metrics_quad            OGG:565-601
 //
 // Kernels:
-//   dpole_eval_kernel + _unwrap_kernel   lam, phi on a lattice of (fractional) indices, exact 360-degree unwrap     -> K5
+//   dpole_mesh_kernel                    integer mesh rows: lam, phi, exact 360-degree unwrap and angle_x in ONE pass   -> K5
+//   dpole_quad_tables / _quad_kernel     Lobatto quadrature of the finite-difference scale factors, nothing in HBM       -> K6
+//   dpole_eval_kernel + _unwrap_kernel   the mesh at arbitrary (fractional) index vectors (drop-in displacedPoleCap_mesh)
 //   dpole_direct_kernel                  displacedPoleCap_projection on explicit grids / bare monotonic_bounding
-//   dpole_h_kernel<F, group>             literal finite-difference scale factors h_i / h_j (numerical_hi / _hj)
-//   dpole_chord_tables / _h_kernel<F>    the same stencil with the chord form of the great-arc distance            -> K6
-//   dpole_quad_reduce_kernel<N>          Lobatto quadrature of h_i, h_j, h_i*h_j per cell                           -> K6
-//
-// monotonic_bounding is a sequential scan along i: column k is lowered by 360 iff v_k - x_{k-1} > 100 where x_{k-1} is the
-// ALREADY ADJUSTED previous column.  With s_k in {0,1} the "was lowered" state, s_k = f_k(s_{k-1}) with
-// f_k(0) = [v_k - v_{k-1} > 100], f_k(1) = [v_k - (v_{k-1} - 360) > 100] -- a composition of 1-bit maps, which is
-// associative.  A workgroup sweeps a row in chunks of SW_TX columns; inside a chunk the maps of all probes (bit-packed,
-// one bit per probe) are composed with a wave64 shuffle scan plus a 4-entry LDS carry, and the state and raw value of the
-// last column are carried to the next chunk.  The comparison values are formed exactly as the reference forms them, so
-// the unwrap is bit-faithful to the sequential loop.
+//   dpole_h_kernel<F, group>             numerical_hi / numerical_hj at arbitrary index vectors
+// The device code of the first two lives in ogg_dpole_dev.h (shared with the fused pass, ogg_pass.hip).
 #include <cstdlib>
 
-#include "ogg_common.h"
-#include "ogg_math.h"
+#include "ogg_dpole_dev.h"
 
 namespace ogg {
 QuadNodes quad_nodes_host(int order);
@@ -29,15 +21,9 @@ QuadNodes quad_nodes_host(int order);
 
 namespace {
 
-using namespace ogg;
-
 constexpr int SW_TX = 256;
-constexpr int SW_WAVES = SW_TX / 64;
 
-struct SweepParams {
-    // geometry of the cap (OGG:478-495)
-    long ni, nj;
-    double lon0, lat0, lam_pole, r_pole;
+struct SweepParams : DpGeom {
     // lattice of the mesh kernel
     long n_cols;          // columns per row
     const double* i_arr;  // column indices or NULL for 0,1,2,...
@@ -46,61 +32,6 @@ struct SweepParams {
     double* out0;         // lam
     double* out1;         // phi
 };
-
-struct DpConst {
-    double z0r, z0i, r_joint;
-};
-
-OGG_DEV DpConst dp_const(const SweepParams& p) {
-    DpConst c;
-    c.r_joint = tan((90 + p.lat0) * kPi180);  // OGG:494
-    double s, co;
-    sincos(p.lam_pole * kPi180, &s, &co);
-    c.z0r = p.r_pole * co;                    // OGG:495
-    c.z0i = p.r_pole * s;
-    return c;
-}
-
-// column-only part of OGG:451-452: e' = (e - z0) / (1 - conj(z0) e)
-OGG_DEV cplx dp_column(double iv, const SweepParams& p, const DpConst& c) {
-    const double lon = p.lon0 + (iv * 360.0) / (double)p.ni;  // OGG:479
-    double s, co;
-    sincos(lon * kPi180, &s, &co);
-    const cplx e = {co, s};
-    const cplx num = {e.re - c.z0r, e.im - c.z0i};
-    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, e);
-    const cplx den = {1.0 - cz.re, 0.0 - cz.im};
-    return cdiv(num, den);
-}
-
-// row-only part of OGG:448: r = tan((90+lat) PI/180) / r_joint
-OGG_DEV double dp_row_radius(double jv, const SweepParams& p, const DpConst& c) {
-    const double lat = -90.0 + (jv * (p.lat0 - (-90.0))) / (double)p.nj;  // OGG:480-482
-    return tan((90 + lat) * kPi180) / c.r_joint;
-}
-
-// per-point remainder of OGG:454-466: raw longitude (before the unwrap) and latitude
-OGG_DEV void dp_point(double r, cplx ep, const DpConst& c, double& lam_raw, double& phi) {
-    const cplx z = {r * ep.re, r * ep.im};
-    const cplx num = {z.re + c.z0r, z.im + c.z0i};
-    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, z);
-    const cplx den = {1 + cz.re, cz.im};
-    const cplx w = cdiv(num, den);
-    lam_raw = atan2(w.im, w.re) * k180Pi;  // np.angle(deg=True)
-    const double rw = cabs_np(w);
-    phi = -90 + div_pi180(atan(rw * c.r_joint));
-}
-
-// OGG:527-532 for point0 = (lam0, phi0), point1 = (lam1, phi1) in degrees
-OGG_DEV double great_arc(double lam0d, double phi0d, double lam1d, double phi1d) {
-    const double lam0 = lam0d * kPi180, phi0 = phi0d * kPi180;
-    const double lam1 = lam1d * kPi180, phi1 = phi1d * kPi180;
-    const double dphi = phi1 - phi0, dlam = lam1 - lam0;
-    const double sp = sin(0.5 * dphi), sl = sin(0.5 * dlam);
-    const double d = sp * sp + sl * sl * cos(phi0) * cos(phi1);
-    return 2.0 * asin(sqrt(d));
-}
-
 
 // ---- monotonic_bounding (OGG:470-475) as a workgroup-wide scan of 1-bit maps ------------------------------------
 template <int NP, int TX = SW_TX>
@@ -168,22 +99,6 @@ OGG_DEV unsigned unwrap_states(const double* v, bool active, bool first_col, con
     unsigned st = carry_state;
     for (int w = 0; w < wave; ++w) st = (st & sh.w1[w]) | (~st & sh.w0[w]);
     return ((st & f1) | (~st & f0)) & ALL;
-}
-
-template <int F>
-OGG_DEV double central_difference(const double* ds, double reps) {  // OGG:539-546
-    if (F == 2) return 0.5 * ds[0] * reps;
-    if (F == 4) return (8.0 * ds[0] - ds[1]) * (1.0 / 12.0) * reps;
-    return (45.0 * ds[0] - 9.0 * ds[1] + ds[2]) * (1.0 / 60.0) * reps;
-}
-
-template <int N>
-OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
-    if (N == 1) return y[0];
-    if (N == 2) return (1.0 / 2.0) * (y[0] + y[1]);
-    if (N == 3) return (1.0 / 6.0) * (4.0 * y[1] + (y[0] + y[2]));
-    if (N == 4) return (1.0 / 12.0) * (5.0 * (y[1] + y[2]) + (y[0] + y[3]));
-    return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
 }
 
 // ---- mesh (OGG:488-518) in two launches ---------------------------------------------------------------------------------
@@ -306,8 +221,7 @@ __global__ __launch_bounds__(SW_TX) void dpole_h_kernel(HParams p) {
     const int tid = threadIdx.x;
     const long row = blockIdx.x;
     double* out = JGROUP ? p.h_j : p.h_i;
-    SweepParams sp{};
-    sp.ni = p.ni, sp.nj = p.nj, sp.lon0 = p.lon0, sp.lat0 = p.lat0, sp.lam_pole = p.lam_pole, sp.r_pole = p.r_pole;
+    const DpGeom sp{p.ni, p.nj, p.lon0, p.lat0, p.lam_pole, p.r_pole};
     const DpConst c = dp_const(sp);
     const double reps = 1.0 / p.eps;
     const int M = p.lattice_M;
@@ -371,171 +285,6 @@ __global__ __launch_bounds__(SW_TX) void dpole_h_kernel(HParams p) {
 }
 
 
-// ---- chord form of the finite-difference scale factors -----------------------------------------------------------------
-// The reference differentiates great-arc distances numerically (OGG:535-562): h = (8 ds(eps) - ds(2 eps)) / (12 eps), where
-// ds is the haversine distance between two projected points that are ~2e-6 rad apart, formed from longitudes/latitudes in
-// degrees.  That subtraction of two O(1) angles loses 10 digits: against an 80-bit evaluation the reference's own h is
-// accurate to 2e-9 (relative).  Here the SAME stencil (the same 4H probe points, the same w = conformal image of each probe)
-// is kept, but the distance between two probes is taken from their positions on the sphere -- from the gnomonic images
-// pa, pb = (X, Y, -1): sin(ds) = |pa x pb| / (|pa| |pb|), see gnomonic_arc -- : no atan2 / atan / hypot per probe, no
-// sin/cos/asin per pair, and no longitude at all -- hence no 360-degree unwrap and no sequential scan.  Its h is accurate to 8e-10 and differs from the reference's by 1.6e-9, i.e. by
-// less than the reference's own rounding error (tests/test_gpu_parity.py bounds it at 5e-7 like the literal path;
-// OGG_DP_LITERAL=1 selects the literal kernels, which numerical_hi / numerical_hj / great_arc_distance always use).
-struct ChordParams {
-    long ni, nj;
-    double lon0, lat0, lam_pole, r_pole, eps;
-    long n_cols, n_rows;   // unique lattice columns / rows
-    int lattice_M;
-    long row0_cell;
-    QuadNodes q;
-    double* row_tab;       // [NV][n_rows]: gnomonic radius of row variants (base, +eps, -eps, +2eps, -2eps)
-    double* col_tab;       // [NV][2][n_cols]: e' of column variants
-    double* h_i;
-    double* h_j;
-};
-
-template <int F>
-__global__ void dpole_chord_tables_kernel(ChordParams p) {
-    constexpr int NV = F + 1;
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    SweepParams sp{};
-    sp.ni = p.ni, sp.nj = p.nj, sp.lon0 = p.lon0, sp.lat0 = p.lat0, sp.lam_pole = p.lam_pole, sp.r_pole = p.r_pole;
-    const DpConst c = dp_const(sp);
-    const int M = p.lattice_M;
-    if (k < p.n_rows * NV) {
-        const long row = k / NV;
-        const int var = (int)(k % NV);
-        double jv = lattice_node(p.q, (int)(row % M), p.row0_cell + row / M);
-        if (var > 0) {
-            const double off = (double)((var + 1) / 2) * p.eps;
-            jv = (var & 1) ? jv + off : jv - off;
-        }
-        p.row_tab[var * p.n_rows + row] = dp_row_radius(jv, sp, c);
-    } else if (k < p.n_rows * NV + p.n_cols * NV) {
-        const long kk = k - p.n_rows * NV;
-        const long col = kk / NV;
-        const int var = (int)(kk % NV);
-        double iv = lattice_node(p.q, (int)(col % M), col / M);
-        if (var > 0) {
-            const double off = (double)((var + 1) / 2) * p.eps;
-            iv = (var & 1) ? iv + off : iv - off;
-        }
-        const cplx ep = dp_column(iv, sp, c);
-        p.col_tab[(var * 2 + 0) * p.n_cols + col] = ep.re;
-        p.col_tab[(var * 2 + 1) * p.n_cols + col] = ep.im;
-    }
-}
-
-struct Gno {
-    double X, Y;   // gnomonic image (plane tangent at the south pole) of a point of the sphere
-};
-
-// w * r_joint, w the conformal image of the probe (OGG:454-455), with the complex quotient formed from one Newton reciprocal
-// of |den|^2 (<= 2 ulp): the point of the sphere is (X, Y, -1) / sqrt(1 + X^2 + Y^2).
-OGG_DEV Gno dp_gnomonic(double r, cplx ep, const DpConst& c) {
-    const double zr = r * ep.re, zi = r * ep.im;
-    const double nr = zr + c.z0r, ni = zi + c.z0i;
-    const double dr = 1 + fma(c.z0r, zr, c.z0i * zi);      // 1 + conj(z0) z
-    const double di = fma(c.z0r, zi, -(c.z0i * zr));
-    const double s = rcp_nr(fma(dr, dr, di * di)) * c.r_joint;
-    return Gno{fma(nr, dr, ni * di) * s, fma(ni, dr, -(nr * di)) * s};
-}
-
-// Great-arc distance of two nearby points from their gnomonic images a, b: with p = (X, Y, -1),
-//   sin(theta) = |pa x pb| / (|pa| |pb|),   |pa x pb|^2 = dX^2 + dY^2 + (Xa dY - Ya dX)^2,   |p|^2 = 1 + X^2 + Y^2
-// -- the differences dX, dY are formed once, nothing is normalised per point, and theta = asin(sin theta) from three terms of
-// the series (the probes of the eps = 1e-3 stencil are ~1e-6 rad apart; exact to 1e-30 below 1e-3).
-OGG_DEV double gnomonic_arc(const Gno& a, const Gno& b) {
-    const double dX = b.X - a.X, dY = b.Y - a.Y;
-    const double cr = fma(a.X, dY, -(a.Y * dX));
-    const double s2 = fma(dX, dX, fma(dY, dY, cr * cr));
-    if (s2 == 0.0) return 0.0;
-    const double na = fma(a.X, a.X, fma(a.Y, a.Y, 1.0)), nb = fma(b.X, b.X, fma(b.Y, b.Y, 1.0));
-    const double q = s2 * rcp_nr(na * nb);            // sin^2(theta)
-    const double sn = sqrt_nr(q);
-    return (sn < 1e-3) ? sn * (1.0 + q * (1.0 / 6.0 + q * (3.0 / 40.0))) : asin(sn);
-}
-
-template <int F>
-__global__ __launch_bounds__(256) void dpole_chord_h_kernel(ChordParams p) {
-    constexpr int H = F / 2, NV = F + 1;
-    const long col = (long)blockIdx.x * 256 + threadIdx.x;
-    const long row = blockIdx.y;
-    if (col >= p.n_cols) return;
-    SweepParams sp{};
-    sp.ni = p.ni, sp.nj = p.nj, sp.lon0 = p.lon0, sp.lat0 = p.lat0, sp.lam_pole = p.lam_pole, sp.r_pole = p.r_pole;
-    const DpConst c = dp_const(sp);
-    const double reps = 1.0 / p.eps;
-    double r[NV];
-    cplx ep[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        r[v] = p.row_tab[v * p.n_rows + row];  // wave-uniform
-        ep[v] = cplx{p.col_tab[(v * 2 + 0) * p.n_cols + col], p.col_tab[(v * 2 + 1) * p.n_cols + col]};
-    }
-    double dsi[(H > 0) ? H : 1], dsj[(H > 0) ? H : 1];
-#pragma unroll
-    for (int m = 1; m <= H; ++m) {
-        // OGG:538,541: ds(j, i + m eps, j, i - m eps);  OGG:553,556: ds(j + m eps, i, j - m eps, i)
-        dsi[m - 1] = gnomonic_arc(dp_gnomonic(r[0], ep[2 * m - 1], c), dp_gnomonic(r[0], ep[2 * m], c));
-        dsj[m - 1] = gnomonic_arc(dp_gnomonic(r[2 * m - 1], ep[0], c), dp_gnomonic(r[2 * m], ep[0], c));
-    }
-    p.h_i[row * p.n_cols + col] = central_difference<F>(dsi, reps);
-    if (p.h_j) p.h_j[row * p.n_cols + col] = central_difference<F>(dsj, reps);
-}
-
-// ---- Lobatto quadrature of the lattice values, one thread per cell, reference summation order (OGG:585-599) --------
-struct ReduceParams {
-    long nx, n_cols;       // cells per row; lattice columns (M*nx + 1)
-    long n_cell_rows;      // cell rows of the band
-    long n_dx_rows;        // n_cell_rows, or n_cell_rows + 1 for the band that owns dxq[ny]
-    double Re;
-    const double* h_i;
-    const double* h_j;
-    double* dxq;
-    double* dyq;
-    double* daq;
-};
-
-template <int N>
-__global__ __launch_bounds__(256) void dpole_quad_reduce_kernel(ReduceParams p) {
-    constexpr int M = N - 1;
-    const long ci = (long)blockIdx.x * 256 + threadIdx.x;
-    const long cj = blockIdx.y;
-    if (ci >= p.nx) return;
-    const double* hi0 = p.h_i + (M * cj) * p.n_cols + M * ci;
-    double yv[N];
-#pragma unroll
-    for (int ii = 0; ii < N; ++ii) yv[ii] = hi0[ii];
-    p.dxq[cj * p.nx + ci] = qavg_1d<N>(yv) * p.Re;                              // OGG:594,598
-    if (cj >= p.n_cell_rows) return;                                          // the dxq[ny] row has no cells
-    const double* hj0 = p.h_j + (M * cj) * p.n_cols + M * ci;
-#pragma unroll
-    for (int jj = 0; jj < N; ++jj) yv[jj] = hj0[jj * p.n_cols];
-    p.dyq[cj * (p.nx + 1) + ci] = qavg_1d<N>(yv) * p.Re;                        // OGG:595,599
-    if (ci == p.nx - 1) {
-#pragma unroll
-        for (int jj = 0; jj < N; ++jj) yv[jj] = hj0[jj * p.n_cols + M];
-        p.dyq[cj * (p.nx + 1) + p.nx] = qavg_1d<N>(yv) * p.Re;
-    }
-    double da;
-    if (N == 2) {
-        const double d = 1.0 / 2.0;
-        da = d * d * (hi0[0] * hj0[0] + hi0[1] * hj0[1] + hi0[p.n_cols] * hj0[p.n_cols] + hi0[p.n_cols + 1] * hj0[p.n_cols + 1]);
-    } else {
-        const double w4[4] = {1.0, 5.0, 5.0, 1.0};
-        const double d = 1.0 / 12.0;
-        double ysum = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < N; ++jj)
-#pragma unroll
-            for (int ii = 0; ii < N; ++ii)
-                ysum = ysum + w4[ii & 3] * w4[jj & 3] * (hi0[jj * p.n_cols + ii] * hj0[jj * p.n_cols + ii]);   // OGG:589,244
-        da = d * d * ysum;
-    }
-    p.daq[cj * p.nx + ci] = da * p.Re * p.Re;                                   // OGG:597
-}
-
 // ---- displacedPoleCap_projection on explicit 2-D lon/lat grids (OGG:447-467) and bare monotonic_bounding ---------
 struct DirectParams {
     long nj, ni;
@@ -584,6 +333,31 @@ __global__ __launch_bounds__(SW_TX) void dpole_direct_kernel(DirectParams p) {
             if (PROJECT) p.phi[row * p.ni + g] = ph;
         }
     }
+}
+
+// ---- kernels around the bodies of ogg_dpole_dev.h -------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void dpole_quad_tables_kernel(DpQuadParams p) {
+    dpole_quad_tables_body<N>(p, blockIdx.x, gridDim.x);
+}
+
+#ifndef OGG_DQ_MINWAVES
+#define OGG_DQ_MINWAVES 2
+#endif
+template <int N, int ARC>
+__global__ __launch_bounds__(64 * DQ_WAVES, OGG_DQ_MINWAVES) void dpole_quad_kernel(DpQuadParams p) {
+    __shared__ unsigned s_slot;
+    const long t = (ARC == DP_ARC_LITERAL) ? take_ticket(p.ticket, &s_slot) : (long)blockIdx.x;
+    dpole_quad_body<N, ARC>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
+}
+
+__global__ __launch_bounds__(256) void dpole_mesh_reset_kernel(DpMeshParams m) { dpole_mesh_reset_body(m, blockIdx.x, gridDim.x); }
+
+__global__ __launch_bounds__(64 * DM_WAVES) void dpole_mesh_kernel(DpMeshParams m) {
+    __shared__ DpMeshLds lds;
+    __shared__ unsigned s_slot;
+    const long t = take_ticket(m.ticket, &s_slot);
+    dpole_mesh_body(m, lds, t % m.gx, t / m.gx);
 }
 
 int launch_mesh(const SweepParams& p, long rows, hipStream_t s) {
@@ -635,16 +409,37 @@ int ogg_monotonic_bounding_dev(long nj, long ni, double* x, double x_0, void* st
     return OGG_OK;
 }
 
-int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0, long nrows,
-                                double* x, double* y, void* stream) {
+long ogg_displaced_pole_grid_workspace_bytes(long Ni, long nrows) {
+    if (Ni <= 0 || nrows < 0) return 0;
+    return (long)dm_workspace_bytes(Ni, nrows);
+}
+
+int ogg_displaced_pole_grid_angle_ws_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0, long nrows,
+                                         double* x, double* y, double* angle_dx, void* workspace, long workspace_bytes, void* stream) {
     if (int e = check_cap(Ni, Nj)) return e;
     OGG_REQUIRE(j0 >= 0 && nrows >= 0 && j0 + nrows <= Nj + 1 && x && y, OGG_ESHAPE,
                 "ogg_displaced_pole_grid: rows %ld..%ld outside 0..%ld", j0, j0 + nrows, Nj);
-    SweepParams p{};
-    p.ni = Ni, p.nj = Nj, p.lon0 = lon0, p.lat0 = lat0, p.lam_pole = lon_dp, p.r_pole = r_dp;
-    p.n_cols = Ni + 1, p.i_arr = nullptr, p.j_arr = nullptr, p.j0 = j0;
-    p.out0 = x, p.out1 = y;
-    return launch_mesh(p, nrows, ogg::as_stream(stream));
+    if (nrows == 0) return OGG_OK;
+    hipStream_t s = ogg::as_stream(stream);
+    ogg::AsyncScratch own(s);
+    void* ws = workspace;
+    long ws_bytes = workspace_bytes;
+    if (!ws) {
+        ws_bytes = (long)dm_workspace_bytes(Ni, nrows);
+        if (int e = own.alloc(&ws, (size_t)ws_bytes)) return e;
+    }
+    DpMeshParams m{};
+    if (int e = plan_dmesh(DpGeom{Ni, Nj, lon0, lat0, lon_dp, r_dp}, j0, nrows, x, y, angle_dx, ws, ws_bytes, m)) return e;
+    dpole_mesh_reset_kernel<<<(unsigned)dm_reset_blocks(m), 256, 0, s>>>(m);
+    OGG_LAUNCH_CHECK();
+    dpole_mesh_kernel<<<(unsigned)dm_blocks(m), 64 * DM_WAVES, 0, s>>>(m);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
+
+int ogg_displaced_pole_grid_dev(long Ni, long Nj, double lon0, double lat0, double lon_dp, double r_dp, long j0, long nrows,
+                                double* x, double* y, void* stream) {
+    return ogg_displaced_pole_grid_angle_ws_dev(Ni, Nj, lon0, lat0, lon_dp, r_dp, j0, nrows, x, y, nullptr, nullptr, 0, stream);
 }
 
 int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, const double* j, long nx, long ny, double lon0,
@@ -675,17 +470,27 @@ int ogg_displaced_pole_numerical_h_dev(long n_i, const double* i, long n_j, cons
 }
 
 long ogg_displaced_pole_quad_workspace_bytes(int order, long nx, long n_cell_rows) {
-    if (order < 2 || order > 5 || nx <= 0 || n_cell_rows < 0) return 0;
-    const long rows = (long)(order - 1) * n_cell_rows + 1, cols = (long)(order - 1) * nx + 1;
-    return (2L * rows * cols + (long)(order + 1) * (rows + 2 * cols)) * (long)sizeof(double);
+    if ((order != 2 && order != 4) || nx <= 0 || n_cell_rows < 0) return 0;
+    return (long)dq_workspace_bytes(order, nx, n_cell_rows);
 }
 
-int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
-                                           double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
-                                           double* daq, void* workspace, long workspace_bytes, void* stream) {
+int ogg_workspace_error_flag_dev(const void* workspace, int* flag, void* stream) {
+    OGG_REQUIRE(workspace && flag, OGG_EARG, "ogg_workspace_error_flag: null pointer");
+    hipStream_t s = ogg::as_stream(stream);
+    unsigned v = 0u;
+    OGG_HIP_CHECK(hipMemcpyAsync(&v, static_cast<const unsigned*>(workspace) + 1, sizeof(v), hipMemcpyDeviceToHost, s));
+    OGG_HIP_CHECK(hipStreamSynchronize(s));
+    *flag = (int)v;
+    return OGG_OK;
+}
+
+int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                                double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
+                                                double* dyq, double* daq, void* workspace, long workspace_bytes, void* stream) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     // the quadrature order is forwarded as the finite-difference order (OGG:583-584): 3 and 5 are "not coded" there
     OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
+    OGG_REQUIRE(arc_form == OGG_DP_ARC_LITERAL || arc_form == OGG_DP_ARC_CHORD, OGG_EARG, "displaced-pole quadrature: arc_form %d", arc_form);
     if (int e = check_cap(nx, ny)) return e;
     OGG_REQUIRE(dxq && (n_cell_rows <= 0 || (dyq && daq)), OGG_EARG, "ogg_displaced_pole_metrics_quad: null output");
     OGG_REQUIRE(j0 >= 0 && n_cell_rows >= 0 && j0 + n_cell_rows <= ny &&
@@ -693,67 +498,48 @@ int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double l
                 OGG_ESHAPE, "ogg_displaced_pole_metrics_quad: band j0=%ld cell rows=%ld dx rows=%ld of ny=%ld", j0,
                 n_cell_rows, n_dx_rows, ny);
     if (n_dx_rows == 0) return OGG_OK;
-    const int M = order - 1;
     hipStream_t s = ogg::as_stream(stream);
-    // lattice rows of the band: the unique Lobatto rows of its cell rows plus the closing row (which is dxq's row j0+n_cell_rows
-    // when the band owns it, and the top edge of the last cell row otherwise)
-    const long n_lat_rows = (long)M * n_cell_rows + 1, n_cols = (long)M * nx + 1;
-    const size_t need = (size_t)ogg_displaced_pole_quad_workspace_bytes(order, nx, n_cell_rows);
+    ogg::AsyncScratch own(s);
     void* ws = workspace;
-    if (workspace)
-        OGG_REQUIRE((size_t)workspace_bytes >= need, OGG_EARG, "displaced-pole quadrature workspace too small: %ld < %zu bytes", workspace_bytes, need);
-    else
-        OGG_HIP_CHECK(hipMallocAsync(&ws, need, s));
-    HParams h{};
-    h.ni = nx, h.nj = ny, h.lon0 = lon0, h.lat0 = lat0, h.lam_pole = lon_dp, h.r_pole = r_dp, h.eps = 1e-3;  // OGG:583
-    h.n_cols = n_cols, h.n_rows = n_lat_rows, h.lattice_M = M, h.row0_cell = j0;
-    h.q = ogg::quad_nodes_host(order);
-    h.h_i = static_cast<double*>(ws);
-    h.h_j = h.h_i + n_lat_rows * n_cols;
-    static const bool literal = getenv("OGG_DP_LITERAL") && atoi(getenv("OGG_DP_LITERAL")) != 0;
-    if (literal) {  // haversine of unwrapped longitudes, operation for operation as OGG:522-562
-        if (order == 2) {
-            dpole_h_kernel<2, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-            if (n_cell_rows > 0) dpole_h_kernel<2, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-        } else {
-            dpole_h_kernel<4, false><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-            if (n_cell_rows > 0) dpole_h_kernel<4, true><<<(unsigned)n_lat_rows, SW_TX, 0, s>>>(h);
-        }
-    } else {  // same stencil, chord form of the distance (see dpole_chord_h_kernel)
-        ChordParams cp{};
-        cp.ni = nx, cp.nj = ny, cp.lon0 = lon0, cp.lat0 = lat0, cp.lam_pole = lon_dp, cp.r_pole = r_dp, cp.eps = 1e-3;
-        cp.n_cols = n_cols, cp.n_rows = n_lat_rows, cp.lattice_M = M, cp.row0_cell = j0, cp.q = h.q;
-        cp.row_tab = h.h_j + n_lat_rows * n_cols;
-        cp.col_tab = cp.row_tab + (long)(order + 1) * n_lat_rows;
-        cp.h_i = h.h_i;
-        cp.h_j = (n_cell_rows > 0) ? h.h_j : nullptr;
-        const long n_tab = (long)(order + 1) * (n_lat_rows + n_cols);
-        dim3 grid((unsigned)((n_cols + 255) / 256), (unsigned)n_lat_rows);
-        if (order == 2) {
-            dpole_chord_tables_kernel<2><<<(unsigned)((n_tab + 255) / 256), 256, 0, s>>>(cp);
-            dpole_chord_h_kernel<2><<<grid, 256, 0, s>>>(cp);
-        } else {
-            dpole_chord_tables_kernel<4><<<(unsigned)((n_tab + 255) / 256), 256, 0, s>>>(cp);
-            dpole_chord_h_kernel<4><<<grid, 256, 0, s>>>(cp);
-        }
+    long ws_bytes = workspace_bytes;
+    if (!ws) {
+        ws_bytes = (long)dq_workspace_bytes(order, nx, n_cell_rows);
+        if (int e = own.alloc(&ws, (size_t)ws_bytes)) return e;
+    }
+    DpQuadParams p{};
+    if (int e = plan_dquad(arc_form, order, DpGeom{nx, ny, lon0, lat0, lon_dp, r_dp}, Re, j0, n_dx_rows, n_cell_rows, dxq, dyq, daq, ws,
+                           ws_bytes, ogg::quad_nodes_host(order), p))
+        return e;
+    const unsigned nwg = (unsigned)(p.gx * p.n_chunks);
+    if (order == 2) {
+        dpole_quad_tables_kernel<2><<<(unsigned)dpole_quad_tables_blocks<2>(p), 256, 0, s>>>(p);
+        if (arc_form == OGG_DP_ARC_CHORD)
+            dpole_quad_kernel<2, DP_ARC_CHORD><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
+        else
+            dpole_quad_kernel<2, DP_ARC_LITERAL><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
+    } else {
+        dpole_quad_tables_kernel<4><<<(unsigned)dpole_quad_tables_blocks<4>(p), 256, 0, s>>>(p);
+        if (arc_form == OGG_DP_ARC_CHORD)
+            dpole_quad_kernel<4, DP_ARC_CHORD><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
+        else
+            dpole_quad_kernel<4, DP_ARC_LITERAL><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
     }
     OGG_LAUNCH_CHECK();
-    ReduceParams r{nx, n_cols, n_cell_rows, n_dx_rows, Re, h.h_i, h.h_j, dxq, dyq, daq};
-    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)n_dx_rows);
-    if (order == 2)
-        dpole_quad_reduce_kernel<2><<<grid, 256, 0, s>>>(r);
-    else
-        dpole_quad_reduce_kernel<4><<<grid, 256, 0, s>>>(r);
-    OGG_LAUNCH_CHECK();
-    if (!workspace) OGG_HIP_CHECK(hipFreeAsync(ws, s));
     return OGG_OK;
+}
+
+int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                           double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
+                                           double* daq, void* workspace, long workspace_bytes, void* stream) {
+    return ogg_displaced_pole_metrics_quad_form_ws_dev(OGG_DP_ARC_LITERAL, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows,
+                                                       n_cell_rows, dxq, dyq, daq, workspace, workspace_bytes, stream);
 }
 
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
                                         double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
                                         double* daq, void* stream) {
-    return ogg_displaced_pole_metrics_quad_ws_dev(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows, n_cell_rows, dxq, dyq,
-                                                  daq, nullptr, 0, stream);
+    return ogg_displaced_pole_metrics_quad_form_ws_dev(OGG_DP_ARC_LITERAL, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows,
+                                                       n_cell_rows, dxq, dyq, daq, nullptr, 0, stream);
 }
 
 }  // extern "C"

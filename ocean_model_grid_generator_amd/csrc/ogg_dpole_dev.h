@@ -1,0 +1,686 @@
+// K5 / K6: displaced-pole Southern cap -- device code (included by ogg_dpole.hip and by the fused pass, ogg_pass.hip).
+//   displacedPoleCap_projection / _mesh      OGG:447-506   (generate_displaced_pole_grid OGG:509-518)
+//   monotonic_bounding                       OGG:470-475
+//   great_arc_distance, numerical_hi/hj      OGG:522-562
+//   displacedPoleCap_metrics_quad            OGG:565-601
+//
+// The quadrature (K6) is fp64-VALU bound: per lattice point the reference re-projects 2*order probe points (complex
+// division, atan2, hypot, atan each) and takes `order` haversines.  Nothing of the lattice is ever written to HBM here: a wave
+// owns 64 consecutive lattice COLUMNS (one per lane) and walks up the lattice rows of its chunk; the Lobatto sums of a cell
+// are formed at the lane of the cell's first column from its right-hand neighbours (DPP wave shifts) and carried from lattice
+// row to lattice row in registers, in the reference's summation order (OGG:216-221, 244-253, 589-599).  Row-only factors
+// (gnomonic radius of the 2*order+1 row variants) are scalar loads from a small table, column-only factors (e' of the
+// column variants, OGG:451-452) stay in registers for the whole walk.
+//
+// monotonic_bounding is a sequential scan along i (column k is lowered by 360 iff v_k - x_{k-1} > 100 with x_{k-1} the ALREADY
+// ADJUSTED previous column).  With s_k in {0,1} the "was lowered" state, s_k = f_k(s_{k-1}) with f_k(0) = [v_k - v_{k-1} > 100],
+// f_k(1) = [v_k - (v_{k-1} - 360) > 100]: 1-bit maps whose composition is associative.  A wave composes the maps of its 64 columns
+// with a shuffle scan, PUBLISHES the composed map of its strip (one 8-byte word per lattice row and strip, relaxed agent-scope
+// atomic store) and reads the words of all strips to its left (relaxed agent-scope atomic loads, bypassing L1) to obtain the
+// state at its first column: a decoupled look-back in which nobody waits for a predecessor's RESULT, only for its strip map,
+// which depends on nothing.  Work items are handed out by an atomic ticket in (rows, strips-fastest) order, so every strip a
+// wave can wait for belongs to a workgroup that is already running: no assumption on dispatch order or residency.  The wait
+// is software-pipelined by one lattice row (row L+1's probes are evaluated between publishing row L and reading its
+// predecessors) and bounded (an error flag is raised instead of spinning forever).  Bit-faithful to the sequential loop.
+#pragma once
+#include <cstdlib>
+
+#include "ogg_common.h"
+#include "ogg_math.h"
+
+namespace {
+
+using namespace ogg;
+
+// ---- pieces of OGG:447-466 ---------------------------------------------------------------------------------------------
+struct DpGeom {      // geometry of the cap (OGG:478-495)
+    long ni, nj;
+    double lon0, lat0, lam_pole, r_pole;
+};
+
+struct DpConst {
+    double z0r, z0i, r_joint;
+};
+
+OGG_DEV DpConst dp_const(const DpGeom& p) {
+    DpConst c;
+    c.r_joint = tan((90 + p.lat0) * kPi180);  // OGG:494
+    double s, co;
+    sincos(p.lam_pole * kPi180, &s, &co);
+    c.z0r = p.r_pole * co;                    // OGG:495
+    c.z0i = p.r_pole * s;
+    return c;
+}
+
+// column-only part of OGG:451-452: e' = (e - z0) / (1 - conj(z0) e)
+OGG_DEV cplx dp_column(double iv, const DpGeom& p, const DpConst& c) {
+    const double lon = p.lon0 + (iv * 360.0) / (double)p.ni;  // OGG:479
+    double s, co;
+    sincos(lon * kPi180, &s, &co);
+    const cplx e = {co, s};
+    const cplx num = {e.re - c.z0r, e.im - c.z0i};
+    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, e);
+    const cplx den = {1.0 - cz.re, 0.0 - cz.im};
+    return cdiv(num, den);
+}
+
+// row-only part of OGG:448: r = tan((90+lat) PI/180) / r_joint
+OGG_DEV double dp_row_radius(double jv, const DpGeom& p, const DpConst& c) {
+    const double lat = -90.0 + (jv * (p.lat0 - (-90.0))) / (double)p.nj;  // OGG:480-482
+    return tan((90 + lat) * kPi180) / c.r_joint;
+}
+
+// per-point remainder of OGG:454-466: raw longitude (before the unwrap) and latitude
+OGG_DEV void dp_point(double r, cplx ep, const DpConst& c, double& lam_raw, double& phi) {
+    const cplx z = {r * ep.re, r * ep.im};
+    const cplx num = {z.re + c.z0r, z.im + c.z0i};
+    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, z);
+    const cplx den = {1 + cz.re, cz.im};
+    const cplx w = cdiv(num, den);
+    lam_raw = atan2(w.im, w.re) * k180Pi;  // np.angle(deg=True)
+    const double rw = cabs_np(w);
+    phi = -90 + div_pi180(atan(rw * c.r_joint));
+}
+
+// OGG:527-532 for point0 = (lam0, phi0), point1 = (lam1, phi1) in degrees
+OGG_DEV double great_arc(double lam0d, double phi0d, double lam1d, double phi1d) {
+    const double lam0 = lam0d * kPi180, phi0 = phi0d * kPi180;
+    const double lam1 = lam1d * kPi180, phi1 = phi1d * kPi180;
+    const double dphi = phi1 - phi0, dlam = lam1 - lam0;
+    const double sp = sin(0.5 * dphi), sl = sin(0.5 * dlam);
+    const double d = sp * sp + sl * sl * cos(phi0) * cos(phi1);
+    return 2.0 * asin(sqrt(d));
+}
+
+template <int F>
+OGG_DEV double central_difference(const double* ds, double reps) {  // OGG:539-546
+    if (F == 2) return 0.5 * ds[0] * reps;
+    if (F == 4) return (8.0 * ds[0] - ds[1]) * (1.0 / 12.0) * reps;
+    return (45.0 * ds[0] - 9.0 * ds[1] + ds[2]) * (1.0 / 60.0) * reps;
+}
+
+template <int N>
+OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
+    if (N == 1) return y[0];
+    if (N == 2) return (1.0 / 2.0) * (y[0] + y[1]);
+    if (N == 3) return (1.0 / 6.0) * (4.0 * y[1] + (y[0] + y[2]));
+    if (N == 4) return (1.0 / 12.0) * (5.0 * (y[1] + y[2]) + (y[0] + y[3]));
+    return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
+}
+
+// sin(x) and asin(x) for |x| < 2^-13 from three terms of their series: the truncation error is below 2^-80 relative, so the
+// result is the correctly rounded value up to the rounding of the last fma (<= 0.5000001 ulp) -- inside the <1 ulp band of
+// any libm, at 5 instructions instead of ocml's range-reduced sin / table-free asin.  The haversine of two probes that are
+// 2e-6 rad apart only ever sees such arguments; anything larger goes to ocml.
+OGG_DEV double sin_tiny(double x) {
+    if (fabs(x) < 0x1p-13) {
+        const double x2 = x * x;
+        return fma(x * x2, fma(x2, 1.0 / 120.0, -1.0 / 6.0), x);
+    }
+    return sin(x);
+}
+OGG_DEV double asin_tiny(double x) {
+    if (fabs(x) < 0x1p-13) {
+        const double x2 = x * x;
+        return fma(x * x2, fma(x2, 3.0 / 40.0, 1.0 / 6.0), x);
+    }
+    return asin(x);
+}
+
+// ---- 1-bit state maps, packed NB to a word -------------------------------------------------------------------------------
+// A map is (m0, m1): the state after it when the state before it was 0 / 1; identity = (0, all).
+OGG_DEV unsigned map_apply(unsigned m0, unsigned m1, unsigned s) { return (s & m1) | (~s & m0); }
+
+// inclusive wave64 scan of the composition (later o earlier) over the lanes
+OGG_DEV void map_scan(unsigned& m0, unsigned& m1) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned e0 = __shfl_up(m0, off), e1 = __shfl_up(m1, off);
+        if (lane >= off) {
+            const unsigned h0 = map_apply(m0, m1, e0), h1 = map_apply(m0, m1, e1);
+            m0 = h0, m1 = h1;
+        }
+    }
+}
+
+constexpr unsigned long long LB_VALID = 1ull << 63;
+constexpr int LB_SPIN_LIMIT = 1 << 20;   // polls before a wave gives up (seconds): raises *err, never reached in a sane launch
+
+OGG_DEV void lb_publish(unsigned long long* word, unsigned m0, unsigned m1) {
+    __hip_atomic_store(word, LB_VALID | (unsigned long long)m0 | ((unsigned long long)m1 << 16), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// State at the first column of strip s of a lattice row: the composition of the published maps of strips 0 .. s-1 (strip 0's
+// map is constant, so the result does not depend on a state before it).  row_words: the row's words, one per strip.  Wave-uniform
+// arguments; all 64 lanes must call.
+OGG_DEV unsigned lb_incoming(const unsigned long long* row_words, long s, unsigned all, int* err) {
+    const int lane = threadIdx.x & 63;
+    unsigned t0 = 0u, t1 = all;
+    for (long base = 0; base < s; base += 64) {
+        const long k = base + lane;
+        const bool have = k < s;
+        unsigned long long w = LB_VALID;
+        int spins = 0;
+        for (;;) {
+            if (have) w = __hip_atomic_load(row_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot((w & LB_VALID) != 0ull) == ~0ull) break;
+            // wave-uniform exits (spins is the same in every lane): give up after LB_SPIN_LIMIT polls, or as soon as another wave
+            // has given up (the call has failed anyway: drain the grid quickly)
+            ++spins;
+            if (spins > LB_SPIN_LIMIT) {
+                if (lane == 0) atomicExch(err, 1);
+                break;
+            }
+            if ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        unsigned m0 = have ? (unsigned)(w & 0xffffull) & all : 0u;
+        unsigned m1 = have ? (unsigned)((w >> 16) & 0xffffull) & all : all;
+        map_scan(m0, m1);
+        const unsigned b0 = __shfl(m0, 63), b1 = __shfl(m1, 63);   // the block's composed map
+        const unsigned n0 = map_apply(b0, b1, t0), n1 = map_apply(b0, b1, t1);
+        t0 = n0, t1 = n1;
+    }
+    return t0 & all;
+}
+
+// work item of a workgroup from an atomic ticket (see the head of this file); one barrier
+OGG_DEV long take_ticket(unsigned* counter, unsigned* s_slot) {
+    if (threadIdx.x == 0) *s_slot = atomicAdd(counter, 1u);
+    __syncthreads();
+    return (long)__builtin_amdgcn_readfirstlane((int)*s_slot);
+}
+
+// ---- quadrature of the finite-difference scale factors (OGG:565-601) ----------------------------------------------------
+constexpr int DQ_WAVES = 4;       // strips per workgroup
+constexpr int DQ_COLS = 63;       // lattice columns a strip owns; lane 63 is the first column of the next strip
+constexpr int DP_ARC_LITERAL = 0; // haversine of the unwrapped longitudes, operation for operation as OGG:522-532
+constexpr int DP_ARC_CHORD = 1;   // same stencil, distance of two probes from their gnomonic images (see dq_chord_point)
+
+struct DpQuadParams {
+    DpGeom g;                    // ni = nx, nj = ny
+    double eps, Re;
+    long j0;                     // first cell row of the band (band-local output row 0)
+    long n_cell_rows, n_dx_rows; // dyq / daq rows; dxq rows (n_cell_rows + 1 on the band that owns row ny)
+    long n_rows, n_cols;         // unique lattice rows of the band (M n_cell_rows + 1), lattice columns (M nx + 1)
+    long rows_per_chunk;         // cell rows one wave walks (its first lattice row is the last one of the chunk below, recomputed)
+    long n_chunks, n_strips, gx; // gx = strip workgroups per chunk
+    QuadNodes q;
+    double* row_tab;             // [NV][n_rows]: gnomonic radius of the row variants (base, +eps, -eps, +2eps, -2eps, ...)
+    double* col_tab;             // [NV][2][n_cols]: e' of the column variants
+    unsigned long long* words;   // [n_chunks][M rows_per_chunk + 1][n_strips]: published strip maps (literal form only)
+    unsigned* ticket;            // work counter; ticket[1] is the error flag
+    double *dxq, *dyq, *daq;
+};
+
+// Row / column tables of one call and the reset of its look-back words; n_words = 0 for the chord form.
+template <int N>
+OGG_DEV void dpole_quad_tables_body(const DpQuadParams& p, long bx, long n_blocks) {
+    constexpr int M = N - 1, NV = N + 1;
+    const long k = bx * blockDim.x + threadIdx.x;
+    const DpConst c = dp_const(p.g);
+    if (k == 0) p.ticket[0] = 0u, p.ticket[1] = 0u;
+    if (k < p.n_rows * NV) {
+        const long row = k / NV;
+        const int var = (int)(k % NV);
+        double jv = lattice_node(p.q, (int)(row % M), p.j0 + row / M);
+        if (var > 0) {
+            const double off = (double)((var + 1) / 2) * p.eps;   // OGG:538-543: j + eps, j + 2.0*eps, ...
+            jv = (var & 1) ? jv + off : jv - off;
+        }
+        p.row_tab[var * p.n_rows + row] = dp_row_radius(jv, p.g, c);
+    } else if (k < p.n_rows * NV + p.n_cols * NV) {
+        const long kk = k - p.n_rows * NV;
+        const long col = kk / NV;
+        const int var = (int)(kk % NV);
+        double iv = lattice_node(p.q, (int)(col % M), col / M);
+        if (var > 0) {
+            const double off = (double)((var + 1) / 2) * p.eps;
+            iv = (var & 1) ? iv + off : iv - off;
+        }
+        const cplx ep = dp_column(iv, p.g, c);
+        p.col_tab[(var * 2 + 0) * p.n_cols + col] = ep.re;
+        p.col_tab[(var * 2 + 1) * p.n_cols + col] = ep.im;
+    }
+    if (p.words) {
+        const long n_words = p.n_chunks * (M * p.rows_per_chunk + 1) * p.n_strips;
+        for (long w = k; w < n_words; w += n_blocks * blockDim.x) p.words[w] = 0ull;
+    }
+}
+
+template <int N>
+inline long dpole_quad_tables_blocks(const DpQuadParams& p) {
+    constexpr int M = N - 1, NV = N + 1;
+    const long n_tab = (p.n_rows + p.n_cols) * NV;
+    const long n_words = p.words ? p.n_chunks * (M * p.rows_per_chunk + 1) * p.n_strips : 0;
+    const long n = n_tab > n_words / 4 ? n_tab : n_words / 4;   // a thread zeroes up to ~4 words
+    return (n + 255) / 256;
+}
+
+// ---- host side: workspace layout and launch plan of one quadrature call (shared with the fused pass) -----------------------
+// workspace: [ticket, error flag, pad (16 B)] [row_tab] [col_tab] [look-back words]
+inline long dq_strips(int order, long nx) { return ((long)(order - 1) * nx + DQ_COLS - 1) / DQ_COLS; }
+
+inline size_t dq_workspace_bytes(int order, long nx, long n_cell_rows) {
+    const long M = order - 1, NV = order + 1;
+    const long n_rows = M * n_cell_rows + 1, n_cols = M * nx + 1;
+    const long n_words = (M + 1) * (n_cell_rows > 0 ? n_cell_rows : 1) * dq_strips(order, nx);   // rows_per_chunk = 1: the largest layout
+    return 16 + (size_t)(NV * (n_rows + 2 * n_cols)) * sizeof(double) + (size_t)n_words * sizeof(unsigned long long);
+}
+
+inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
+                      double* dyq, double* daq, void* ws, long ws_bytes, const QuadNodes& q, DpQuadParams& p) {
+    const long M = order - 1, NV = order + 1;
+    const size_t need = dq_workspace_bytes(order, g.ni, n_cell_rows);
+    OGG_REQUIRE(ws && (size_t)ws_bytes >= need, OGG_EARG, "displaced-pole quadrature workspace too small: %ld < %zu bytes", ws_bytes, need);
+    p.g = g;
+    p.eps = 1e-3;   // OGG:583
+    p.Re = Re;
+    p.j0 = j0, p.n_cell_rows = n_cell_rows, p.n_dx_rows = n_dx_rows;
+    p.n_rows = M * n_cell_rows + 1, p.n_cols = M * g.ni + 1;
+    p.n_strips = dq_strips(order, g.ni);
+    p.gx = (p.n_strips + DQ_WAVES - 1) / DQ_WAVES;
+    // enough waves to fill 1024 SIMDs several times over without recomputing more than a few % of the lattice rows
+    long target = 8192;
+    if (const char* ev = getenv("OGG_DPQUAD_TARGET_WAVES")) target = atol(ev) > 0 ? atol(ev) : target;
+    long rpc = (n_cell_rows * p.n_strips + target - 1) / target;
+    p.rows_per_chunk = rpc < 1 ? 1 : (rpc > 32 ? 32 : rpc);
+    p.n_chunks = n_cell_rows > 0 ? (n_cell_rows + p.rows_per_chunk - 1) / p.rows_per_chunk : 1;
+    p.q = q;
+    p.ticket = static_cast<unsigned*>(ws);
+    p.row_tab = reinterpret_cast<double*>(static_cast<char*>(ws) + 16);
+    p.col_tab = p.row_tab + NV * p.n_rows;
+    p.words = (arc_form == DP_ARC_LITERAL) ? reinterpret_cast<unsigned long long*>(p.col_tab + NV * 2 * p.n_cols) : nullptr;
+    p.dxq = dxq, p.dyq = dyq, p.daq = daq;
+    return OGG_OK;
+}
+
+// -- chord form ------------------------------------------------------------------------------------------------------------
+// The reference differentiates great-arc distances numerically (OGG:535-562): h = (8 ds(eps) - ds(2 eps)) / (12 eps), where
+// ds is the haversine distance between two projected points that are ~2e-6 rad apart, formed from longitudes/latitudes in
+// degrees.  That subtraction of two O(1) angles loses 10 digits: against an 80-bit evaluation the reference's own h is
+// accurate to 2e-9 (relative).  The chord form keeps the SAME stencil (the same probe points, the same conformal image w of
+// each probe) but takes the distance between two probes from their positions on the sphere -- from the gnomonic images
+// pa, pb = (X, Y, -1): sin(ds) = |pa x pb| / (|pa| |pb|) -- : no atan2 / atan / hypot per probe, no sin/cos/asin per pair and
+// no longitude at all, hence no unwrap.  Its h is accurate to 8e-10 and differs from the reference's by ~1.6e-9, i.e. by less
+// than the reference's own rounding error, but it is NOT the reference's arithmetic: it is an explicit option (arc_form = 1),
+// the literal form is the default everywhere.
+struct Gno {
+    double X, Y;   // gnomonic image (plane tangent at the south pole) of a point of the sphere
+};
+
+// w * r_joint, w the conformal image of the probe (OGG:454-455), with the complex quotient formed from one Newton reciprocal
+// of |den|^2 (<= 2 ulp): the point of the sphere is (X, Y, -1) / sqrt(1 + X^2 + Y^2).
+OGG_DEV Gno dp_gnomonic(double r, cplx ep, const DpConst& c) {
+    const double zr = r * ep.re, zi = r * ep.im;
+    const double nr = zr + c.z0r, ni = zi + c.z0i;
+    const double dr = 1 + fma(c.z0r, zr, c.z0i * zi);      // 1 + conj(z0) z
+    const double di = fma(c.z0r, zi, -(c.z0i * zr));
+    const double s = rcp_nr(fma(dr, dr, di * di)) * c.r_joint;
+    return Gno{fma(nr, dr, ni * di) * s, fma(ni, dr, -(nr * di)) * s};
+}
+
+// Great-arc distance of two nearby points from their gnomonic images a, b: with p = (X, Y, -1),
+//   sin(theta) = |pa x pb| / (|pa| |pb|),   |pa x pb|^2 = dX^2 + dY^2 + (Xa dY - Ya dX)^2,   |p|^2 = 1 + X^2 + Y^2
+OGG_DEV double gnomonic_arc(const Gno& a, const Gno& b) {
+    const double dX = b.X - a.X, dY = b.Y - a.Y;
+    const double cr = fma(a.X, dY, -(a.Y * dX));
+    const double s2 = fma(dX, dX, fma(dY, dY, cr * cr));
+    if (s2 == 0.0) return 0.0;
+    const double na = fma(a.X, a.X, fma(a.Y, a.Y, 1.0)), nb = fma(b.X, b.X, fma(b.Y, b.Y, 1.0));
+    const double q = s2 * rcp_nr(na * nb);            // sin^2(theta)
+    const double sn = sqrt_nr(q);
+    return (sn < 1e-3) ? sn * (1.0 + q * (1.0 / 6.0 + q * (3.0 / 40.0))) : asin(sn);
+}
+
+// -- one lattice row, one column per lane ---------------------------------------------------------------------------------
+// Pair k of the stencil: k < H: (j, i + m eps) / (j, i - m eps), m = k + 1 (h_i, OGG:538,541); k >= H: (j + m eps, i) / (j - m eps, i),
+// m = k - H + 1 (h_j, OGG:553,556).  Probe 2k is the "+" point (point 0 of great_arc_distance), probe 2k+1 the "-" point.
+template <int F>
+struct DqPending {       // literal form: raw longitude and latitude (degrees) of the two probes of each pair
+    double va[F], vb[F];
+    double pa[F], pb[F];
+};
+
+template <int F>
+OGG_DEV void dq_probe_pair(int k, const double* r, const cplx* ep, double& ra, double& rb, cplx& epa, cplx& epb) {
+    constexpr int H = F / 2;
+    // r[v], ep[v]: variant v of the row radius / of e' (0: base, 2m-1: +m eps, 2m: -m eps); selects instead of dynamic indexing
+    ra = rb = r[0];
+    epa = epb = ep[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        if (k == m - 1) epa = ep[2 * m - 1], epb = ep[2 * m];
+        if (k == H + m - 1) ra = r[2 * m - 1], rb = r[2 * m];
+    }
+}
+
+#ifndef OGG_DQ_UNROLL
+#define OGG_DQ_UNROLL 1   // pairs evaluated one after the other: interleaving the libm calls of several probes costs registers
+#endif
+
+// phase 1 of the literal form: all probes of this lane's lattice point (OGG:522-526, 454-466), ONE at a time (two projections
+// in flight need 60 more registers than one)
+template <int F>
+OGG_DEV void dq_literal_probes(const double* r, const cplx* ep, const DpConst& c, DqPending<F>& o) {
+#pragma unroll OGG_DQ_UNROLL
+    for (int q = 0; q < 2 * F; ++q) {
+        const int k = q >> 1;
+        double ra, rb;
+        cplx epa, epb;
+        dq_probe_pair<F>(k, r, ep, ra, rb, epa, epb);
+        const bool minus = (q & 1) != 0;
+        double v, ph;
+        dp_point(minus ? rb : ra, minus ? epb : epa, c, v, ph);
+#pragma unroll
+        for (int t = 0; t < F; ++t) {
+            o.va[t] = (q == 2 * t) ? v : o.va[t];
+            o.vb[t] = (q == 2 * t + 1) ? v : o.vb[t];
+            o.pa[t] = (q == 2 * t) ? ph : o.pa[t];
+            o.pb[t] = (q == 2 * t + 1) ? ph : o.pb[t];
+        }
+    }
+}
+
+// phase 2, once the unwrap states are known: the haversines (OGG:527-532) and the central differences.  st = packed "was lowered
+// by 360" states of this lane's 2F probes (bit 2k: "+" probe of pair k)
+template <int F>
+OGG_DEV void dq_literal_finish(const DqPending<F>& o, unsigned st, double reps, double& hi, double& hj) {
+    constexpr int H = F / 2;
+    double ds[F];
+#pragma unroll OGG_DQ_UNROLL
+    for (int k = 0; k < F; ++k) {
+        double va = o.va[0], vb = o.vb[0], pha = o.pa[0], phb = o.pb[0];
+#pragma unroll
+        for (int q = 1; q < F; ++q) {
+            va = (k == q) ? o.va[q] : va, vb = (k == q) ? o.vb[q] : vb;
+            pha = (k == q) ? o.pa[q] : pha, phb = (k == q) ? o.pb[q] : phb;
+        }
+        const double xa = ((st >> (2 * k)) & 1u) ? va - 360 : va;            // OGG:473
+        const double xb = ((st >> (2 * k + 1)) & 1u) ? vb - 360 : vb;
+        const double lam0 = xa * kPi180, phi0 = pha * kPi180;               // OGG:527-528
+        const double lam1 = xb * kPi180, phi1 = phb * kPi180;
+        const double dphi = phi1 - phi0, dlam = lam1 - lam0;
+        const double sp = sin_tiny(0.5 * dphi), sl = sin_tiny(0.5 * dlam);
+        const double d = sp * sp + sl * sl * cos(phi0) * cos(phi1);         // OGG:531
+        const double dsk = 2.0 * asin_tiny(sqrt(d));
+#pragma unroll
+        for (int q = 0; q < F; ++q) ds[q] = (k == q) ? dsk : ds[q];
+    }
+    hi = central_difference<F>(ds, reps);
+    hj = central_difference<F>(ds + H, reps);
+}
+
+template <int F>
+OGG_DEV void dq_chord_point(const double* r, const cplx* ep, const DpConst& c, double reps, double& hi, double& hj) {
+    constexpr int H = F / 2;
+    double ds[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        double ra, rb;
+        cplx epa, epb;
+        dq_probe_pair<F>(k, r, ep, ra, rb, epa, epb);
+        ds[k] = gnomonic_arc(dp_gnomonic(ra, epa, c), dp_gnomonic(rb, epb, c));
+    }
+    hi = central_difference<F>(ds, reps);
+    hj = central_difference<F>(ds + H, reps);
+}
+
+template <int N>
+OGG_DEV double dq_weight(int k) {  // w[k] of OGG:240 (order 4); order 2 sums the four corners unweighted (OGG:229-232)
+    if (N == 4) return (k == 0 || k == 3) ? 1.0 : 5.0;
+    return 1.0;
+}
+
+// Strip `strip` of chunk `chunk`: all 64 lanes of the wave call; strip, chunk wave-uniform.
+template <int N, int ARC>
+OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
+    constexpr int M = N - 1, F = N, NV = F + 1;
+    constexpr unsigned ALL = (1u << (2 * F)) - 1u;
+    const int lane = threadIdx.x & 63;
+    const long u0 = strip * DQ_COLS;
+    if (u0 >= p.n_cols - 1) return;              // wave-uniform: nothing but another strip's halo column (n_cols >= 2)
+    const long u = u0 + lane;                    // this lane's lattice column
+    const bool valid = u < p.n_cols;
+    const long uc = valid ? u : p.n_cols - 1;
+    const long ci = uc / M;                      // cell
+    const bool cell_start = valid && (uc % M == 0);
+    const bool out_lane = cell_start && ci < p.g.ni && lane <= 63 - M;
+    const bool dy_edge = cell_start && ci == p.g.ni;    // first node column of cell nx: dyq[.][nx]
+    const DpConst c = dp_const(p.g);
+    const double reps = 1.0 / p.eps;
+    cplx ep[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ep[v] = cplx{p.col_tab[(v * 2 + 0) * p.n_cols + uc], p.col_tab[(v * 2 + 1) * p.n_cols + uc]};
+
+    const long r0 = chunk * p.rows_per_chunk;                     // band-local first cell row of the chunk
+    const long nc = (p.n_cell_rows - r0 < p.rows_per_chunk) ? p.n_cell_rows - r0 : p.rows_per_chunk;   // cell rows of the chunk (>= 0)
+    const long n_lat = M * nc + 1;                                // lattice rows the wave evaluates
+    const bool own_top = (p.n_dx_rows > p.n_cell_rows) && (r0 + nc == p.n_cell_rows);
+    unsigned long long* words = p.words + (chunk * (M * p.rows_per_chunk + 1)) * p.n_strips;
+
+    // quadrature state of the cell row in progress
+    double dyc[N], ysum = 0.0, dxv = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) dyc[k] = 0.0;
+
+    DqPending<F> pend, pend_next;
+    unsigned inc0 = 0u, inc1 = ALL, inc0_next = 0u, inc1_next = ALL;   // inclusive strip-local maps of this lane
+    double chi = 0.0, chj = 0.0;                                       // chord form: the scale factors themselves
+#pragma unroll
+    for (int k = 0; k < F; ++k) pend.va[k] = pend.vb[k] = pend.pa[k] = pend.pb[k] = 0.0;
+    pend_next = pend;
+
+#pragma unroll 1
+    for (long L = -1; L < n_lat; ++L) {
+        // ---- evaluate lattice row L + 1 ------------------------------------------------------------------------------
+        if (L + 1 < n_lat) {
+            const long row = M * r0 + L + 1;      // band-local lattice row
+            double r[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) r[v] = p.row_tab[v * p.n_rows + row];   // wave-uniform
+            if (ARC == DP_ARC_CHORD) {
+                dq_chord_point<F>(r, ep, c, reps, pend_next.va[0], pend_next.vb[0]);
+            } else {
+                dq_literal_probes<F>(r, ep, c, pend_next);
+                // maps of this column (OGG:471-474): one bit per probe
+                unsigned f0 = 0u, f1 = 0u;
+#pragma unroll
+                for (int k = 0; k < F; ++k) {
+                    const double va = pend_next.va[k], vb = pend_next.vb[k];
+                    const double pa = wave_prev(va), pb = wave_prev(vb);
+                    bool a0, a1, b0, b1;
+                    if (u == 0) {  // column 0 is compared with lon_grid[0,0] of its probe mesh (OGG:463), no state before it
+                        constexpr int H = F / 2;
+                        const double off = (k < H) ? (double)(k + 1) * p.eps : 0.0;
+                        const double i_first = lattice_node(p.q, 0, 0);
+                        a0 = a1 = (va - (p.g.lon0 + ((i_first + off) * 360.0) / (double)p.g.ni) > 100);
+                        b0 = b1 = (vb - (p.g.lon0 + ((i_first - off) * 360.0) / (double)p.g.ni) > 100);
+                    } else {
+                        a0 = (va - pa > 100), a1 = (va - (pa - 360) > 100);   // previous column not lowered / lowered
+                        b0 = (vb - pb > 100), b1 = (vb - (pb - 360) > 100);
+                    }
+                    f0 |= ((a0 ? 1u : 0u) << (2 * k)) | ((b0 ? 1u : 0u) << (2 * k + 1));
+                    f1 |= ((a1 ? 1u : 0u) << (2 * k)) | ((b1 ? 1u : 0u) << (2 * k + 1));
+                }
+                // lane 0's column belongs to the strip on the left (its state is the incoming state); columns past the row end: identity
+                if ((lane == 0 && u != 0) || !valid) f0 = 0u, f1 = ALL;
+                map_scan(f0, f1);
+                inc0_next = f0, inc1_next = f1;
+                if (lane == 63) lb_publish(words + (L + 1) * p.n_strips + strip, f0, f1);
+            }
+        }
+        // ---- finish lattice row L and feed it to the quadrature ---------------------------------------------------------
+        if (L >= 0) {
+            double hi, hj;
+            if (ARC == DP_ARC_CHORD) {
+                hi = chi, hj = chj;
+            } else {
+                const unsigned s_in = (strip > 0) ? lb_incoming(words + L * p.n_strips, strip, ALL, (int*)(p.ticket + 1)) : 0u;
+                dq_literal_finish<F>(pend, map_apply(inc0, inc1, s_in), reps, hi, hj);
+            }
+            const long k = L / M;                 // cell row of the chunk this lattice row is the row jj of
+            const int jj = (int)(L % M);
+            const double pr = hi * hj;            // OGG:589
+            double ah[N], ap[N];                  // h_i and h_i h_j at this column and its M right-hand neighbours
+            ah[0] = hi, ap[0] = pr;
+#pragma unroll
+            for (int i = 1; i < N; ++i) ah[i] = wave_next(ah[i - 1]), ap[i] = wave_next(ap[i - 1]);
+            if (jj == 0 && k > 0) {               // top edge of cell row k - 1: its last Lobatto row
+#pragma unroll
+                for (int i = 0; i < N; ++i) ysum = ysum + dq_weight<N>(i) * dq_weight<N>(M) * ap[i];   // OGG:244 / 231
+                dyc[M] = hj;
+                const long out_r = r0 + k - 1;
+                const double d = (N == 2) ? (1.0 / 2.0) : (1.0 / 12.0);
+                if (out_lane) {
+                    p.dxq[out_r * p.g.ni + ci] = dxv;
+                    p.dyq[out_r * (p.g.ni + 1) + ci] = qavg_1d<N>(dyc) * p.Re;                        // OGG:595,599
+                    p.daq[out_r * p.g.ni + ci] = (d * d * ysum) * p.Re * p.Re;                        // OGG:597
+                }
+                if (dy_edge) p.dyq[out_r * (p.g.ni + 1) + p.g.ni] = qavg_1d<N>(dyc) * p.Re;
+            }
+            if (k < nc) {
+                if (jj == 0) {
+                    dxv = qavg_1d<N>(ah) * p.Re;                                                       // OGG:594,598
+                    ysum = 0.0;
+                }
+                const double wj = dq_weight<N>(jj);
+#pragma unroll
+                for (int i = 0; i < N; ++i) ysum = ysum + dq_weight<N>(i) * wj * ap[i];
+#pragma unroll
+                for (int q = 0; q < N; ++q) dyc[q] = (jj == q) ? hj : dyc[q];
+            } else if (own_top && out_lane) {     // L = M nc: the j = ny lattice row, dxq only
+                p.dxq[(r0 + nc) * p.g.ni + ci] = qavg_1d<N>(ah) * p.Re;
+            }
+        }
+        pend = pend_next;
+        inc0 = inc0_next, inc1 = inc1_next;
+        chi = pend_next.va[0], chj = pend_next.vb[0];
+    }
+}
+
+// ---- mesh (OGG:488-518) fused with the unwrap and angle_x (OGG:719-729), rows j0 .. j0+nrows-1 -----------------------------
+// A wave owns 62 output columns plus one halo column on either side (the i-1 / i+1 neighbours of angle_x are wave shifts, the
+// mesh is never read back); the unwrap state at the wave's first column comes from the strips to its left by the same
+// look-back as the quadrature's.  Row-only radius once per row of the workgroup (LDS), column-only e' once per lane.
+constexpr int DM_WAVES = 4;
+constexpr int DM_OUT = 62;
+constexpr int DM_ROWS = 8;
+
+struct DpMeshParams {
+    DpGeom g;                    // ni = Ni, nj = Nj
+    long j0, nrows;
+    double *x, *y, *angle;       // angle may be NULL
+    unsigned long long* words;   // [nrows][n_strips]
+    unsigned* ticket;            // ticket[0]: work counter, ticket[1]: error flag
+    long n_strips, gx;           // strips per row; strip workgroups per row tile
+    int rows_per_wg;
+};
+
+struct DpMeshLds {
+    DpConst c;
+    double r[DM_ROWS];
+};
+
+OGG_DEV void dpole_mesh_body(const DpMeshParams& m, DpMeshLds& s, long bx, long by) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long Ni = m.g.ni, ni1 = Ni + 1;
+    const long jl0 = by * m.rows_per_wg;
+    const int nr = (int)((m.nrows - jl0 < m.rows_per_wg) ? (m.nrows - jl0) : m.rows_per_wg);
+    if (tid == 0) s.c = dp_const(m.g);
+    __syncthreads();
+    if (tid < nr) s.r[tid] = dp_row_radius((double)(m.j0 + jl0 + tid), m.g, s.c);
+    __syncthreads();
+    const long strip = bx * DM_WAVES + wave;
+    const long col0 = strip * DM_OUT;                     // first output column of this wave
+    if (col0 > Ni) return;                                // wave-uniform
+    long i = col0 - 1 + lane;
+    const bool in_row = (i >= 0) && (i <= Ni);
+    i = i < 0 ? 0 : (i > Ni ? Ni : i);
+    const bool out = (lane >= 1) && (lane <= DM_OUT) && in_row;
+    const DpConst c = s.c;
+    const cplx ep = dp_column((double)i, m.g, c);
+    const double seed = m.g.lon0 + (0.0 * 360.0) / (double)Ni;   // lon_grid[0,0] (OGG:463)
+    double v_cur = 0.0, ph_cur = 0.0, v_nxt = 0.0, ph_nxt = 0.0;
+    unsigned i0 = 0u, i1 = 1u, n0 = 0u, n1 = 1u;
+#pragma unroll 1
+    for (int r = -1; r < nr; ++r) {
+        if (r + 1 < nr) {
+            dp_point(s.r[r + 1], ep, c, v_nxt, ph_nxt);
+            const double vp = wave_prev(v_nxt);
+            unsigned f0, f1;
+            if (lane == 0 || !in_row) {
+                f0 = 0u, f1 = 1u;                         // the halo column on the left belongs to the previous strip
+            } else if (i == 0) {
+                f0 = f1 = (v_nxt - seed > 100) ? 1u : 0u; // OGG:471-472
+            } else {
+                f0 = (v_nxt - vp > 100) ? 1u : 0u;        // OGG:473-474
+                f1 = (v_nxt - (vp - 360) > 100) ? 1u : 0u;
+            }
+            map_scan(f0, f1);
+            n0 = f0, n1 = f1;
+            // the strip's own map: its columns col0 .. col0+61 are lanes 1 .. 62
+            if (lane == DM_OUT) lb_publish(m.words + (jl0 + r + 1) * m.n_strips + strip, f0, f1);
+        }
+        if (r >= 0) {
+            const long jl = jl0 + r;
+            const unsigned s_in = (strip > 0) ? lb_incoming(m.words + jl * m.n_strips, strip, 1u, (int*)(m.ticket + 1)) : 0u;
+            const unsigned st = map_apply(i0, i1, s_in);
+            const double lam = st ? v_cur - 360 : v_cur;  // OGG:473
+            const double phi = ph_cur;
+            if (out) {
+                m.x[jl * ni1 + i] = lam;
+                m.y[jl * ni1 + i] = phi;
+            }
+            if (m.angle) {                                // OGG:725-728, literal
+                const double xl = wave_prev(lam), xr = wave_next(lam);
+                const double yl = wave_prev(phi), yr = wave_next(phi);
+                const double cy = cos(phi * kPi180);
+                double a;
+                if (i == 0)
+                    a = atan2(yr - phi, (xr - lam) * cy);
+                else if (i == Ni)
+                    a = atan2(phi - yl, (lam - xl) * cy);
+                else
+                    a = atan2(yr - yl, (xr - xl) * cy);
+                if (out) m.angle[jl * ni1 + i] = div_pi180(a);
+            }
+        }
+        v_cur = v_nxt, ph_cur = ph_nxt;
+        i0 = n0, i1 = n1;
+    }
+}
+
+// reset of the look-back words and the ticket of one mesh call (its own small launch, or part of launch A of the pass)
+OGG_DEV void dpole_mesh_reset_body(const DpMeshParams& m, long bx, long n_blocks) {
+    const long k = bx * blockDim.x + threadIdx.x;
+    if (k == 0) m.ticket[0] = 0u, m.ticket[1] = 0u;
+    const long n_words = m.nrows * m.n_strips;
+    for (long w = k; w < n_words; w += n_blocks * blockDim.x) m.words[w] = 0ull;
+}
+
+// workspace: [ticket, error flag, pad (16 B)] [look-back words: nrows x n_strips]
+inline long dm_strips(long Ni) { return (Ni + 1 + DM_OUT - 1) / DM_OUT; }
+inline size_t dm_workspace_bytes(long Ni, long nrows) { return 16 + (size_t)(nrows * dm_strips(Ni)) * sizeof(unsigned long long); }
+
+inline int plan_dmesh(const DpGeom& g, long j0, long nrows, double* x, double* y, double* angle, void* ws, long ws_bytes, DpMeshParams& m) {
+    const size_t need = dm_workspace_bytes(g.ni, nrows);
+    OGG_REQUIRE(ws && (size_t)ws_bytes >= need, OGG_EARG, "displaced-pole mesh workspace too small: %ld < %zu bytes", ws_bytes, need);
+    m.g = g;
+    m.j0 = j0, m.nrows = nrows;
+    m.x = x, m.y = y, m.angle = angle;
+    m.ticket = static_cast<unsigned*>(ws);
+    m.words = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 16);
+    m.n_strips = dm_strips(g.ni);
+    m.gx = (m.n_strips + DM_WAVES - 1) / DM_WAVES;
+    long rpw = DM_ROWS;
+    if (const char* e = getenv("OGG_DPMESH_ROWS")) rpw = atol(e) < 1 ? 1 : (atol(e) > DM_ROWS ? DM_ROWS : atol(e));
+    m.rows_per_wg = (int)rpw;
+    return OGG_OK;
+}
+inline long dm_blocks(const DpMeshParams& m) { return m.gx * ((m.nrows + m.rows_per_wg - 1) / m.rows_per_wg); }
+inline long dm_reset_blocks(const DpMeshParams& m) { return (m.nrows * m.n_strips / 4 + 256) / 256; }
+
+}  // namespace
