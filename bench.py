@@ -44,7 +44,7 @@ ALG_BYTES = {
     "angle_x": ("point", 24),         # x, y read + angle_dx written
     "bipolar_mesh": ("point", 24),    # x, y, angle_dx written; no reads
     "bipolar_quad": ("point", 24),    # dx, dy, area written; no reads
-    "dpole_mesh": ("point", 16),
+    "dpole_mesh": ("point", 24),      # x, y, angle_dx written (mesh, unwrap and angle in one launch); no reads
     "dpole_quad": ("point", 24),
 }
 
@@ -66,7 +66,6 @@ def band_points(plan, rank, world, sg_mod):
         else:
             pts.setdefault("dpole_mesh", []).append(n)
             pts.setdefault("dpole_quad", []).append(n)
-            pts.setdefault("angle_x", []).append(n)
     return pts
 
 
@@ -157,6 +156,10 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
     ap.add_argument("--d2h", type=int, default=1, help="after the timed region: time the copy of this rank's bands to pinned host memory (information)")
     ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
+    ap.add_argument("--dp-arc", default="chord", choices=["chord", "literal"],
+                    help="arc form of the displaced-pole quadrature (workloads with a displaced pole only): chord (same finite-difference "
+                         "stencil, distances from the probes' positions on the sphere) or literal (the reference's haversine arithmetic); "
+                         "both are ~1.3e-9 relative from the CPU oracle at 1/8 degree (see `parity` on the output line)")
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
                     help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
                          "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
@@ -181,7 +184,7 @@ def main():
     from ocean_model_grid_generator_amd import _lib, supergrid
 
     flags = WORKLOADS[args.workload]
-    plan = supergrid.SupergridPlan(**flags)
+    plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **flags)
     if args.as_rank is not None:  # single-GPU rehearsal of one rank's share
         sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device=device, halo="recompute", latlon=args.latlon)
     else:
@@ -211,8 +214,6 @@ def main():
         tuned = {}
         # (the pass is launched eagerly: a graph of its three launches gains nothing and would hide them from the events)
         cands = [("pass", 0, 0), ("kernels", 1, 1), ("kernels", 0, 0)]
-        if has_dp:  # the displaced-pole cap on a side stream next to the pass
-            cands += [("pass", 1, 0)]
         for launch, overlap, graph in cands:
             sg.launch, sg.overlap = launch, bool(overlap)
             if graph and not can_graph:
@@ -294,7 +295,7 @@ def main():
             d2h = {"error": repr(exc)}
     # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
     # stream (events cannot be read back from inside a replayed graph)
-    timed_launch = "%s%s%s" % (sg.launch, ", caps on side streams" if (sg.launch == "kernels" and sg.overlap) else (", displaced-pole cap on a side stream" if (sg.overlap and has_dp) else ""),
+    timed_launch = "%s%s%s" % (sg.launch, ", caps on side streams" if (sg.launch == "kernels" and sg.overlap) else "",
                                ", hip graph replay" if use_graph else ", eager")
     sg._events = {}
     sg.launch = "kernels"
@@ -326,7 +327,8 @@ def main():
                 v.update({"ms": round(v["ms"], 5), "alg_bytes": int(v["alg_bytes"]), "alg_GBps": round(gbs, 1),
                           "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
             dom = max(launches, key=lambda k: launches[k]["ms"])
-            roof = {"kernel": {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5>", "pass_tail": "bipolar_quad_tail_kernel<5>"}[dom],
+            roof = {"kernel": {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5>", "pass_tail": "bipolar_quad_tail_kernel<5>",
+                               "pass_dpquad": "pass_d_kernel<4>"}[dom],
                     "bound": "hbm", "achieved": launches[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": launches[dom]["hbm_frac"], "traffic": pmc.get(dom),
                     "note": "longest of the three launches of the fused pass; HIP events recorded by the library on the launch stream in "
@@ -346,7 +348,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
-                       "flags": flags, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
+                       "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
                        "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
                            world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
             "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned,

@@ -28,9 +28,13 @@ extern "C" {
 #define OGG_ENOMEM 4 /* device allocation failed */
 #define OGG_EARG 5   /* null pointer / invalid scalar */
 
+#define OGG_DP_ARC_LITERAL 0 /* arc form of the displaced-pole quadrature: see ogg_displaced_pole_metrics_quad_form_ws_dev */
+#define OGG_DP_ARC_CHORD 1
+
 const char* ogg_last_error(void);
 const char* ogg_version(void);
-/* sizeof(ogg_latlon_band) for which = 0, sizeof(ogg_bipolar_band) for which = 1 (-1 otherwise): lets a binding verify its layout */
+/* sizeof(ogg_latlon_band) for which = 0, sizeof(ogg_bipolar_band) for which = 1, sizeof(ogg_dpole_band) for which = 2 (-1
+ * otherwise): lets a binding verify its layout */
 long ogg_abi_sizeof(int which);
 int ogg_device_count(int* count);
 int ogg_set_device(int device);
@@ -249,8 +253,7 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
  *   OGG_DP_ARC_CHORD    same stencil, distance from the gnomonic images of the probes (no atan2 / unwrap): ~7x less arithmetic,
  *                       ~1.6e-9 relative from the reference's value (the reference's own rounding error there is ~2e-9), against
  *                       ~1e-10 for the literal form.  Opt-in only. */
-#define OGG_DP_ARC_LITERAL 0
-#define OGG_DP_ARC_CHORD 1
+/* (OGG_DP_ARC_LITERAL = 0, OGG_DP_ARC_CHORD = 1: defined next to the error codes at the top of this file) */
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                         double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
                                         double* dxq, double* dyq, double* daq, void* stream);
@@ -269,6 +272,33 @@ int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, do
                                     double Re, double* dxq, double* dyq, double* daq);
 int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                          double r_dp, double Re, double* dxq, double* dyq, double* daq);
+
+/* One rank's share of a whole supergrid: ogg_tripolar_pass_dev plus the band of a displaced-pole southern cap (the SC branch of
+ * the same sub-grid loop, OGG:1158-1197: generate_displaced_pole_grid + angle_x + displacedPoleCap_metrics_quad) in the SAME
+ * launches: its tables and the reset of its look-back words join launch A, its mesh + angle workgroups and -- in the chord form --
+ * its quadrature strips join launch B; the literal form of the quadrature is a fourth launch (D) on the same stream.  Results are
+ * bit-identical to ogg_displaced_pole_grid_angle_ws_dev + ogg_displaced_pole_metrics_quad_form_ws_dev on the same band.
+ * south_cap may be NULL.  events5 (NULL, or 5 events, entries may be NULL): before A, after A, B, C, D; alg_bytes4: bytes each
+ * launch writes. */
+typedef struct ogg_dpole_band {
+    long Ni, Nj;                 /* the cap is (Nj+1) x (Ni+1) points (OGG:509) */
+    double lon0, lat0;           /* OGG:478: first longitude, latitude of the joint with the Southern Ocean sub-grid */
+    double lon_dp, r_dp;         /* OGG:495: longitude and radius of the displaced pole */
+    double Re;
+    int order;                   /* Gauss-Lobatto order of the quadrature = finite-difference order: 2 or 4 (OGG:583-584) */
+    int arc_form;                /* OGG_DP_ARC_LITERAL or OGG_DP_ARC_CHORD */
+    long j0;                     /* first mesh row of the band (rows below the doughnut cut are simply never asked for) */
+    long n_pt_rows;              /* point rows: x, y, angle (n_pt_rows x (Ni+1)), dx (n_pt_rows x Ni) */
+    long n_cell_rows;            /* cell rows: dy (n_cell_rows x (Ni+1)), area (n_cell_rows x Ni); n_pt_rows - 1 on the band that holds
+                                    row Nj, else n_pt_rows */
+    double *x, *y, *angle, *dx, *dy, *area;
+    void* workspace;             /* >= ogg_dpole_band_workspace_bytes(order, Ni, n_pt_rows) bytes of device memory */
+    long workspace_bytes;
+} ogg_dpole_band;
+long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows);
+int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                           const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** events5, double* alg_bytes4,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Device utilities used by the band-sharded pipeline (bench / multi-GPU)

@@ -33,6 +33,14 @@ class BipolarBand(ctypes.Structure):
                 ("workspace_bytes", c_long)]
 
 
+class DpoleBand(ctypes.Structure):
+    """ogg_dpole_band of include/ogg_hip.h"""
+    _fields_ = [("Ni", c_long), ("Nj", c_long), ("lon0", c_double), ("lat0", c_double), ("lon_dp", c_double), ("r_dp", c_double),
+                ("Re", c_double), ("order", c_int), ("arc_form", c_int), ("j0", c_long), ("n_pt_rows", c_long), ("n_cell_rows", c_long),
+                ("x", c_void_p), ("y", c_void_p), ("angle", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_long)]
+
+
 # name -> argtypes; every function returns int except the two string getters.  Must list EVERY symbol of ogg_hip.h
 # (tests/test_abi.py checks this list against the header).
 SIGNATURES = {
@@ -112,6 +120,9 @@ SIGNATURES = {
                               ctypes.POINTER(BipolarBand), c_void_p],
     "ogg_tripolar_pass_events_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
                                      ctypes.POINTER(BipolarBand), ctypes.POINTER(c_void_p), ctypes.POINTER(c_double), c_void_p],
+    "ogg_supergrid_pass_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
+                               ctypes.POINTER(BipolarBand), ctypes.POINTER(DpoleBand), ctypes.POINTER(c_void_p), ctypes.POINTER(c_double),
+                               c_void_p],
     "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],
@@ -126,7 +137,8 @@ STRING_GETTERS = ("ogg_last_error", "ogg_version")
 LONG_GETTERS = {"ogg_abi_sizeof": [c_int],
                 "ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long],
                 "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long],
-                "ogg_displaced_pole_grid_workspace_bytes": [c_long, c_long]}
+                "ogg_displaced_pole_grid_workspace_bytes": [c_long, c_long],
+                "ogg_dpole_band_workspace_bytes": [c_int, c_long, c_long]}
 
 _lib = None
 

@@ -70,7 +70,8 @@ const char* ogg_last_error(void) { return ogg::g_err; }
 const char* ogg_version(void) { return "ogg_hip 0.1 (gfx950)"; }
 // sizeof of the descriptor structs of the ABI (0: ogg_latlon_band, 1: ogg_bipolar_band), so that a binding can check its layout
 long ogg_abi_sizeof(int which) {
-    return which == 0 ? (long)sizeof(ogg_latlon_band) : (which == 1 ? (long)sizeof(ogg_bipolar_band) : -1L);
+    return which == 0 ? (long)sizeof(ogg_latlon_band)
+                      : (which == 1 ? (long)sizeof(ogg_bipolar_band) : (which == 2 ? (long)sizeof(ogg_dpole_band) : -1L));
 }
 
 int ogg_device_count(int* count) {

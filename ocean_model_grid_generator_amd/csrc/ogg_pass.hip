@@ -1,26 +1,34 @@
-// One rank's whole pass over a tripolar supergrid (the sub-grid loop of OGG:1100-1313) in THREE launches on one stream.
+// One rank's whole pass over a tripolar supergrid (the sub-grid loop of OGG:1100-1313) in THREE launches on one stream (four
+// when a displaced-pole southern cap asks for the literal arc form, whose quadrature kernel needs more registers than the
+// workgroups of launch B should be held to).
 //
 // The lat-lon sub-grids are HBM-write bound (48 B/cell, a few waves per CU saturate the write path), the bipolar cap is
 // fp64-VALU bound (mesh: asin/atan/atan2 per point; quadrature: (N-1)^2 lattice points per cell).  Instead of putting them
 // on separate streams -- which costs 10-20 us of cross-queue signalling per dependency, as much as the kernels themselves
 // once the grid is split over 8 GPUs -- each launch carries workgroups of BOTH kinds, told apart by their workgroup index:
 //
-//   launch A:  row/column tables of the quadrature (a few microseconds)
-//   launch B:  lat-lon row strips  |  cap mesh + angle  |  quadrature strips with the guard  |  quadrature strips without
-//   launch C:  literal fix-up of the cells the guard handed over  |  j = ny row of the quadrature (literal)
-// (without metrics there is no quadrature: launch A then carries the lat-lon strips and the mesh, and B, C do not exist)
+//   launch A:  row/column tables of the quadratures (both caps), reset of the displaced-pole look-back words (a few microseconds)
+//   launch B:  lat-lon row strips  |  bipolar mesh + angle  |  displaced-pole mesh + angle  |  bipolar quadrature strips with the
+//              guard  |  ... without  |  displaced-pole quadrature strips (chord form)
+//   launch C:  literal fix-up of the bipolar cells the guard handed over  |  j = ny row of the bipolar quadrature (literal)
+//   launch D:  displaced-pole quadrature strips, literal form (only when asked for)
+// (without metrics and without a displaced-pole cap there is no quadrature: launch A then carries the lat-lon strips and the
+// bipolar mesh, and B, C do not exist)
 //
 // The lat-lon workgroups come first in the index space (they are resident from the start and walk their strips grid-stride
 // while the compute workgroups stream through the remaining slots).  Every workgroup runs the same body function as the
 // stand-alone kernels of ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level
 // entry points.
 #include "ogg_bipolar_dev.h"
+#include "ogg_dpole_dev.h"
 #include "ogg_latlon_fused_dev.h"
 
 namespace {
 
 constexpr int PASS_TX = 256;
-static_assert(PASS_TX == LF_TX && PASS_TX == 64 * MESH_WAVES && PASS_TX == 64 * QS_WAVES, "one workgroup shape for all roles");
+static_assert(PASS_TX == LF_TX && PASS_TX == 64 * MESH_WAVES && PASS_TX == 64 * QS_WAVES && PASS_TX == 64 * DM_WAVES &&
+                  PASS_TX == 64 * DQ_WAVES,
+              "one workgroup shape for all roles");
 
 struct LatlonShare {
     long n_wg;      // workgroups of this launch that stream lat-lon strips (gx * gy)
@@ -31,6 +39,7 @@ struct LatlonShare {
 union PassLds {
     RowScalars ll[LF_ROWS + 1];
     BpRow mesh[MESH_ROWS];
+    DpMeshLds dmesh;
 };
 
 struct PassAParams {
@@ -39,7 +48,12 @@ struct PassAParams {
     MeshParams mesh;
     long mesh_gx, n_mesh;   // mesh workgroups: mesh_gx column tiles x row tiles
     QuadParams q;
-    long n_tab;             // workgroups of the tables
+    long n_tab;             // workgroups of the bipolar tables
+    DpQuadParams dq;        // displaced-pole cap: tables of its quadrature ...
+    long n_dq_tab;
+    int dq_order;
+    DpMeshParams dm;        // ... and the reset of the look-back words of its mesh
+    long n_dm_reset;
 };
 
 template <int N>
@@ -56,6 +70,19 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
         return;
     }
     b -= a.n_tab;
+    if (b < a.n_dq_tab) {
+        if (a.dq_order == 2)
+            dpole_quad_tables_body<2>(a.dq, b, a.n_dq_tab);
+        else
+            dpole_quad_tables_body<4>(a.dq, b, a.n_dq_tab);
+        return;
+    }
+    b -= a.n_dq_tab;
+    if (b < a.n_dm_reset) {
+        dpole_mesh_reset_body(a.dm, b, a.n_dm_reset);
+        return;
+    }
+    b -= a.n_dm_reset;
     if (b < a.n_mesh) bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
 }
 
@@ -67,11 +94,17 @@ struct PassBParams {
     QuadParams q;
     QuadRange guard, fast;
     long gx, n_guard, n_fast;
+    DpMeshParams dm;        // displaced-pole cap: mesh + unwrap + angle ...
+    long n_dmesh;
+    DpQuadParams dq;        // ... and its quadrature in the chord form (the literal form is launch D)
+    long n_dquad;
+    int dq_order;
 };
 
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ PassLds lds;
+    __shared__ unsigned s_slot;
     long b = blockIdx.x;
     if (b < a.share.n_wg) {
         latlon_fused_body(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
@@ -83,12 +116,37 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
         return;
     }
     b -= a.n_mesh;
+    if (b < a.n_dmesh) {   // work item from the ticket, not from the workgroup index: see ogg_dpole_dev.h
+        const long t = take_ticket(a.dm.ticket, &s_slot);
+        dpole_mesh_body(a.dm, lds.dmesh, t % a.dm.gx, t / a.dm.gx);
+        return;
+    }
+    b -= a.n_dmesh;
     if (b < a.n_guard) {
         bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
         return;
     }
     b -= a.n_guard;
-    if (b < a.n_fast) bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
+    if (b < a.n_fast) {
+        bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
+        return;
+    }
+    b -= a.n_fast;
+    if (b < a.n_dquad) {
+        const long strip = (b % a.dq.gx) * DQ_WAVES + (threadIdx.x >> 6), chunk = b / a.dq.gx;
+        if (a.dq_order == 2)
+            dpole_quad_body<2, DP_ARC_CHORD>(a.dq, strip, chunk);
+        else
+            dpole_quad_body<4, DP_ARC_CHORD>(a.dq, strip, chunk);
+    }
+}
+
+// launch D: the displaced-pole quadrature in the reference's literal arithmetic (238 VGPRs: its own launch)
+template <int N>
+__global__ __launch_bounds__(PASS_TX, 2) void pass_d_kernel(DpQuadParams p) {
+    __shared__ unsigned s_slot;
+    const long t = take_ticket(p.ticket, &s_slot);
+    dpole_quad_body<N, DP_ARC_LITERAL>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
 }
 
 long env_long(const char* name, long dflt) {
@@ -134,17 +192,27 @@ double latlon_strip_bytes(const FusedParams& ll, long lo, long hi) {
     return bytes;
 }
 
+// bytes the displaced-pole band writes: mesh + angle (launch B), quadrature (launch B or D)
+double dpole_mesh_bytes(const ogg_dpole_band& d) { return 8.0 * 3.0 * (double)d.n_pt_rows * (double)(d.Ni + 1); }
+double dpole_quad_bytes(const ogg_dpole_band& d) {
+    return 8.0 * ((double)d.n_pt_rows * (double)d.Ni + (double)d.n_cell_rows * (2.0 * (double)d.Ni + 1.0));
+}
+
 template <int N>
-int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, hipEvent_t* ev, double* alg_bytes3,
-                hipStream_t st) {
-    // ev: NULL, or 4 events recorded before launch A and after launches A, B and C (bench.py times the launches with them)
+int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, const ogg_dpole_band* scap, hipEvent_t* ev,
+                double* alg_bytes4, hipStream_t st) {
+    // ev: NULL, or 5 events (entries may be NULL) recorded before launch A and after launches A, B, C and D (bench.py times the
+    // launches with them)
     auto mark = [&](int k) -> int {
-        if (ev) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
+        if (ev && ev[k]) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
         return OGG_OK;
     };
     const long n_strips_ll = ll.n_bands ? ll.strip0[ll.n_bands] : 0;
     const bool have_cap = cap && cap->n_pt_rows > 0;
     const bool have_quad = have_cap && metrics;
+    const bool have_dp = scap && scap->n_pt_rows > 0;
+    const bool have_dquad = have_dp && metrics;
+    const bool dq_literal = have_dquad && scap->arc_form == OGG_DP_ARC_LITERAL;
     PassAParams A{};
     PassBParams B{};
     QuadPlan qp{};
@@ -167,26 +235,48 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.gx * qp.guard.gy : 0;
         B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.gx * qp.fast.gy : 0;
     }
-    // With metrics, launch A builds only the tables and launch B carries everything else, the cap mesh included: one long launch
-    // in which all three kinds of workgroup overlap (measured faster than mesh + part of the lat-lon strips in A at every share
-    // from 1 to 1/8 of the 1/8 degree grid).  Without metrics there is no launch B: A carries the lat-lon strips and the mesh.
-    const bool launch_b = have_quad && (B.n_guard + B.n_fast > 0);
+    DpQuadParams dq{};
+    if (have_dp) {   // workspace of the band: [mesh words][quadrature tables and words]
+        const DpGeom g{scap->Ni, scap->Nj, scap->lon0, scap->lat0, scap->lon_dp, scap->r_dp};
+        const long mesh_ws = (long)((dm_workspace_bytes(scap->Ni, scap->n_pt_rows) + 255) / 256 * 256);
+        OGG_REQUIRE(scap->workspace && scap->workspace_bytes >= mesh_ws, OGG_EARG, "ogg_supergrid_pass: displaced-pole workspace too small");
+        if (int e = plan_dmesh(g, scap->j0, scap->n_pt_rows, scap->x, scap->y, scap->angle, scap->workspace, mesh_ws, B.dm)) return e;
+        A.dm = B.dm;
+        A.n_dm_reset = dm_reset_blocks(B.dm);
+        B.n_dmesh = dm_blocks(B.dm);
+        if (have_dquad) {
+            if (int e = plan_dquad(scap->arc_form, scap->order, g, scap->Re, scap->j0, scap->n_pt_rows, scap->n_cell_rows, scap->dx, scap->dy,
+                                   scap->area, static_cast<char*>(scap->workspace) + mesh_ws, scap->workspace_bytes - mesh_ws,
+                                   make_nodes(scap->order), dq))
+                return e;
+            A.dq = dq, A.dq_order = scap->order;
+            A.n_dq_tab = scap->order == 2 ? dpole_quad_tables_blocks<2>(dq) : dpole_quad_tables_blocks<4>(dq);
+            if (!dq_literal) B.dq = dq, B.dq_order = scap->order, B.n_dquad = dq.gx * dq.n_chunks;
+        }
+    }
+    // With metrics, launch A builds only the tables and launch B carries everything else, the cap meshes included: one long launch
+    // in which all kinds of workgroup overlap (measured faster than mesh + part of the lat-lon strips in A at every share
+    // from 1 to 1/8 of the 1/8 degree grid).  Without metrics and without a displaced-pole cap there is no launch B: A carries the
+    // lat-lon strips and the bipolar mesh.  (The displaced-pole mesh cannot run in A: its look-back words are reset there.)
+    const bool launch_b = (have_quad && (B.n_guard + B.n_fast > 0)) || have_dp;
     const long s1 = launch_b ? 0 : n_strips_ll;   // lat-lon strips [0, s1) in launch A, [s1, S) in launch B
     if (launch_b) {
         B.mesh = A.mesh, B.mesh_gx = A.mesh_gx, B.n_mesh = A.n_mesh;
         A.n_mesh = 0;
     }
-    if (alg_bytes3) {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
+    if (alg_bytes4) {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
         const double ni = (double)(ni1 - 1);
         const double mesh_bytes = have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0;
-        alg_bytes3[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes);
-        alg_bytes3[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) +
-                                       mesh_bytes
+        const double bq_bytes = have_quad ? 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) : 0.0;
+        alg_bytes4[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes);
+        alg_bytes4[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + bq_bytes + mesh_bytes + (have_dp ? dpole_mesh_bytes(*scap) : 0.0) +
+                                       ((have_dquad && !dq_literal) ? dpole_quad_bytes(*scap) : 0.0)
                                  : 0.0;
-        alg_bytes3[2] = (have_quad && qp.has_top) ? 8.0 * ni : 0.0;
+        alg_bytes4[2] = (have_quad && qp.has_top) ? 8.0 * ni : 0.0;
+        alg_bytes4[3] = dq_literal ? dpole_quad_bytes(*scap) : 0.0;
     }
-    A.share = make_share(ll, 0, s1, ni1, !have_cap);
-    const long na = A.share.n_wg + A.n_tab + A.n_mesh;
+    A.share = make_share(ll, 0, s1, ni1, !have_cap && !have_dp);
+    const long na = A.share.n_wg + A.n_tab + A.n_dq_tab + A.n_dm_reset + A.n_mesh;
     if (int e = mark(0)) return e;
     if (na > 0) {
         pass_a_kernel<N><<<(unsigned)na, PASS_TX, 0, st>>>(A);
@@ -195,7 +285,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     if (int e = mark(1)) return e;
     if (launch_b) {
         B.share = make_share(ll, s1, n_strips_ll, ni1, false);
-        const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_guard + B.n_fast);
+        const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
         OGG_LAUNCH_CHECK();
     }
@@ -203,13 +293,28 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     if (have_quad) {
         if (int e = launch_quad_tail<N>(qp, st)) return e;
     }
-    return mark(3);
+    if (int e = mark(3)) return e;
+    if (dq_literal) {
+        const unsigned nd = (unsigned)(dq.gx * dq.n_chunks);
+        if (scap->order == 2)
+            pass_d_kernel<2><<<nd, PASS_TX, 0, st>>>(dq);
+        else
+            pass_d_kernel<4><<<nd, PASS_TX, 0, st>>>(dq);
+        OGG_LAUNCH_CHECK();
+    }
+    return mark(4);
 }
 
 }  // namespace
 
-extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
-                                            int metrics, const ogg_bipolar_band* cap, void** events4, double* alg_bytes3, void* stream) {
+extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows) {
+    if ((order != 2 && order != 4) || Ni <= 0 || n_pt_rows < 0) return 0;
+    return (long)((dm_workspace_bytes(Ni, n_pt_rows) + 255) / 256 * 256) + (long)dq_workspace_bytes(order, Ni, n_pt_rows);
+}
+
+extern "C" int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                                      const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** events5, double* alg_bytes4,
+                                      void* stream) {
     FusedParams ll;
     long points = 0;
     if (int e = plan_latlon(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, ll, points)) return e;
@@ -231,17 +336,49 @@ extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band*
             OGG_REQUIRE(cap->workspace, OGG_EARG, "ogg_tripolar_pass: the cap needs a workspace (ogg_bipolar_quad_workspace_bytes)");
         }
     }
-    hipStream_t st = ogg::as_stream(stream);
-    hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(events4);
-    switch (order) {
-        case 2: return launch_pass<2>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
-        case 3: return launch_pass<3>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
-        case 4: return launch_pass<4>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
-        default: return launch_pass<5>(ll, ni1, metrics, cap, ev, alg_bytes3, st);
+    if (south_cap && south_cap->n_pt_rows > 0) {
+        const ogg_dpole_band& d = *south_cap;
+        OGG_REQUIRE(d.Ni + 1 == ni1, OGG_ESHAPE, "ogg_supergrid_pass: southern cap has %ld columns, the lat-lon bands %ld", d.Ni + 1, ni1);
+        OGG_REQUIRE(d.Nj > 0 && d.j0 >= 0 && d.j0 + d.n_pt_rows <= d.Nj + 1, OGG_ESHAPE,
+                    "ogg_supergrid_pass: southern cap rows %ld..%ld outside 0..%ld", d.j0, d.j0 + d.n_pt_rows, d.Nj);
+        OGG_REQUIRE(d.x && d.y && d.angle, OGG_EARG, "ogg_supergrid_pass: null southern cap output");
+        OGG_REQUIRE(d.workspace && d.workspace_bytes >= ogg_dpole_band_workspace_bytes(metrics ? d.order : 4, d.Ni, d.n_pt_rows), OGG_EARG,
+                    "ogg_supergrid_pass: the southern cap needs a workspace of ogg_dpole_band_workspace_bytes bytes");
+        if (metrics) {
+            OGG_REQUIRE(d.order >= 2 && d.order <= 5, OGG_EORDER, "Uncoded order");
+            OGG_REQUIRE(d.order == 2 || d.order == 4, OGG_EORDER, "order not coded");   // OGG:547: the quadrature order is the FD order
+            OGG_REQUIRE(d.arc_form == OGG_DP_ARC_LITERAL || d.arc_form == OGG_DP_ARC_CHORD, OGG_EARG, "ogg_supergrid_pass: arc_form %d", d.arc_form);
+            OGG_REQUIRE(d.dx && (d.n_cell_rows <= 0 || (d.dy && d.area)), OGG_EARG, "ogg_supergrid_pass: null southern cap metrics output");
+            OGG_REQUIRE(d.n_cell_rows >= 0 && d.j0 + d.n_cell_rows <= d.Nj &&
+                            (d.n_pt_rows == d.n_cell_rows || (d.n_pt_rows == d.n_cell_rows + 1 && d.j0 + d.n_cell_rows == d.Nj)),
+                        OGG_ESHAPE, "ogg_supergrid_pass: southern cap band j0=%ld cell rows=%ld point rows=%ld of Nj=%ld", d.j0, d.n_cell_rows,
+                        d.n_pt_rows, d.Nj);
+        }
     }
+    hipStream_t st = ogg::as_stream(stream);
+    hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(events5);
+    switch (order) {
+        case 2: return launch_pass<2>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
+        case 3: return launch_pass<3>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
+        case 4: return launch_pass<4>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
+        default: return launch_pass<5>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
+    }
+}
+
+extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
+                                            int metrics, const ogg_bipolar_band* cap, void** events4, double* alg_bytes3, void* stream) {
+    void* ev5[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double by4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (events4)
+        for (int k = 0; k < 4; ++k) ev5[k] = events4[k];
+    const int rc = ogg_supergrid_pass_dev(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, nullptr, events4 ? ev5 : nullptr,
+                                          alg_bytes3 ? by4 : nullptr, stream);
+    if (alg_bytes3)
+        for (int k = 0; k < 3; ++k) alg_bytes3[k] = by4[k];
+    return rc;
 }
 
 extern "C" int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
                                      int metrics, const ogg_bipolar_band* cap, void* stream) {
-    return ogg_tripolar_pass_events_dev(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, nullptr, nullptr, stream);
+    return ogg_supergrid_pass_dev(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, nullptr, nullptr, nullptr, stream);
 }

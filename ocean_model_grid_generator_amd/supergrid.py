@@ -4,11 +4,11 @@ One process per GPU.  Every rank owns a contiguous band of rows of EACH sub-grid
 Mercator, bipolar cap): cost per row differs by ~100x between the lat-lon sub-grids and the caps, so cutting the
 stitched grid into contiguous slabs would not balance.  One pass (default pipeline, ``latlon="fused"``, ``launch="pass"``) is
 
-  ogg_tripolar_pass_dev   three launches on the caller's stream: the quadrature tables; then ONE launch that carries the
+  ogg_supergrid_pass_dev  three launches on the caller's stream: the quadrature tables; then ONE launch that carries the
                           lat-lon row strips (x, y, dx, dy, area, angle_dx from the axis formulas: 48 B written per cell,
-                          nothing read), the bipolar mesh + angle and the bipolar quadrature strips side by side; then the
-                          literal fix-up of the guarded cells
-  displaced-pole cap      its own kernels (mesh, angle, quadrature), on one side stream next to the pass
+                          nothing read), the mesh + angle workgroups of both caps and their quadrature strips side by side; then
+                          the literal fix-up of the guarded bipolar cells (a displaced-pole quadrature in the reference's literal
+                          arc form, ``dp_arc="literal"``, is a fourth launch: it needs more registers than launch B should have)
 
 with no exchange between ranks: the caps are analytic in (i, j) and the lat-lon kernel needs only the axis formulas.
 ``launch="kernels"`` runs one launch per sub-grid and phase instead (the caps on side streams when ``overlap`` is set) and gives
@@ -68,11 +68,13 @@ class SupergridPlan(object):
     latitudes are read back from device-computed values, exactly as main() reads them from phiMerc."""
 
     def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0,
-                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, Re=ogg._default_Re, mercator_axis=None):
+                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, Re=ogg._default_Re, mercator_axis=None, dp_arc="literal"):
         """``mercator_axis`` = (y0, phi_M) lets a caller that already holds the Mercator ordinate range and axis skip the
-        two device calls (the CPU tests of the band / halo logic pass values computed elsewhere)."""
+        two device calls (the CPU tests of the band / halo logic pass values computed elsewhere).  ``dp_arc``: arc form of
+        the displaced-pole quadrature, "literal" (the reference's arithmetic) or "chord" (include/ogg_hip.h)."""
         refineS, refineR = 2, inverse_resolution
         self.Re = Re
+        self.dp_arc = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[dp_arc]
         self.skip_metrics = skip_metrics
         self.south_cutoff_row = south_cutoff_row
         self.lon0, self.lenlon = -300.0, 360.0
@@ -223,9 +225,10 @@ class Supergrid(object):
                 elif s.kind == "bipolar":
                     b["ws_bytes"] = int(L.load().ogg_bipolar_quad_workspace_bytes(5, plan.Ni, s.Nj))
                     b["ws"] = torch.empty(b["ws_bytes"], dtype=torch.uint8, device=self.device)
-                elif s.kind == "dpole" and not plan.skip_metrics:
-                    b["ws_bytes"] = int(L.load().ogg_displaced_pole_quad_workspace_bytes(4, plan.Ni, b["n_cell"]))
-                    b["ws"] = torch.empty(b["ws_bytes"], dtype=torch.uint8, device=self.device)
+                elif s.kind == "dpole":   # one workspace for the pass (mesh words + quadrature tables and words); the stand-alone
+                    b["ws_bytes"] = int(L.load().ogg_dpole_band_workspace_bytes(4, plan.Ni, n))   # kernels use its two parts
+                    b["ws"] = torch.empty(max(b["ws_bytes"], 16), dtype=torch.uint8, device=self.device)
+                    b["ws_mesh_bytes"] = (int(L.load().ogg_displaced_pole_grid_workspace_bytes(plan.Ni, n)) + 255) // 256 * 256
                 self.buf[s.name] = b
 
     @staticmethod
@@ -284,12 +287,12 @@ class Supergrid(object):
         return bands
 
     def tripolar_pass(self):
-        """Lat-lon sub-grids and the bipolar cap of this rank through ogg_tripolar_pass_dev."""
+        """Lat-lon sub-grids and both caps of this rank through ogg_supergrid_pass_dev."""
         p, st = self.plan, self._stream()
         if self._pass_args is None:  # the descriptors only hold scalars and buffer addresses, which never change: build once
             bands = self._latlon_bands()
             arr = (L.LatlonBand * max(len(bands), 1))(*bands)
-            cap = None
+            cap = scap = None
             for s in p.subs:
                 b = self.buf[s.name]
                 if s.kind == "bipolar" and b["n"] > 0:
@@ -301,23 +304,35 @@ class Supergrid(object):
                     cap.dy = b["dy"].data_ptr() if b["n_cell"] else None
                     cap.area = b["area"].data_ptr() if b["n_cell"] else None
                     cap.workspace, cap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
-            self._pass_args = (bands, arr, cap)
-        bands, arr, cap = self._pass_args
+                elif s.kind == "dpole" and b["n"] > 0:
+                    scap = L.DpoleBand()
+                    scap.Ni, scap.Nj, scap.lon0, scap.lat0, scap.lon_dp, scap.r_dp, scap.Re = p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp, p.Re
+                    scap.order, scap.arc_form = 4, p.dp_arc
+                    scap.j0, scap.n_pt_rows, scap.n_cell_rows = s.row0 + b["lo"], b["n"], b["n_cell"]
+                    scap.x, scap.y, scap.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
+                    scap.dx = b["dx"].data_ptr()
+                    scap.dy = b["dy"].data_ptr() if b["n_cell"] else None
+                    scap.area = b["area"].data_ptr() if b["n_cell"] else None
+                    scap.workspace, scap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
+            self._pass_args = (bands, arr, cap, scap)
+        bands, arr, cap, scap = self._pass_args
         capref = ctypes.byref(cap) if cap is not None else None
+        scapref = ctypes.byref(scap) if scap is not None else None
         if self.pass_events is None:
-            L.call("ogg_tripolar_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, st)
+            L.call("ogg_supergrid_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, scapref,
+                   None, None, st)
             return
-        # per-launch timing: four HIP events recorded by the library around its three launches
+        # per-launch timing: five HIP events recorded by the library around its (up to) four launches
         evs = self._event_pool.pop() if self._event_pool else self._new_events()
-        self.pass_bytes = (ctypes.c_double * 3)()
-        L.call("ogg_tripolar_pass_events_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, evs,
+        self.pass_bytes = (ctypes.c_double * 4)()
+        L.call("ogg_supergrid_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, scapref, evs,
                self.pass_bytes, st)
         self.pass_events.append(evs)
 
     @staticmethod
     def _new_events():
-        evs = (ctypes.c_void_p * 4)()
-        for k in range(4):
+        evs = (ctypes.c_void_p * 5)()
+        for k in range(5):
             e = ctypes.c_void_p()
             L.call("ogg_event_create", ctypes.byref(e))
             evs[k] = e
@@ -328,21 +343,21 @@ class Supergrid(object):
         self._event_pool = [self._new_events() for _ in range(n)]
 
     def pass_launch_times_ms(self):
-        """Mean duration and algorithmic bytes of the three launches of the fused pass over the passes that ran while
-        `pass_events` was a list; empties the list."""
+        """Mean duration and algorithmic bytes of the four launches of the fused pass (the fourth exists only with a displaced-pole
+        cap in the literal arc form) over the passes that ran while `pass_events` was a list; empties the list."""
         L.call("ogg_stream_synchronize", self._stream())
-        tot = [0.0, 0.0, 0.0]
+        tot = [0.0, 0.0, 0.0, 0.0]
         n = len(self.pass_events)
         for evs in self.pass_events:
-            for k in range(3):
+            for k in range(4):
                 ms = ctypes.c_float()
                 L.call("ogg_event_elapsed_ms", evs[k], evs[k + 1], ctypes.byref(ms))
                 tot[k] += ms.value
-            for k in range(4):
+            for k in range(5):
                 L.call("ogg_event_destroy", evs[k])
         self.pass_events = []
-        by = list(self.pass_bytes) if n else [0.0, 0.0, 0.0]
-        out = {name: {"ms": tot[k] / max(n, 1), "alg_bytes": by[k]} for k, name in enumerate(("pass_a", "pass_b", "pass_tail"))}
+        by = list(self.pass_bytes) if n else [0.0, 0.0, 0.0, 0.0]
+        out = {name: {"ms": tot[k] / max(n, 1), "alg_bytes": by[k]} for k, name in enumerate(("pass_a", "pass_b", "pass_tail", "pass_dpquad"))}
         out["sampled_passes"] = n
         return out
 
@@ -375,12 +390,10 @@ class Supergrid(object):
             elif s.kind == "bipolar":
                 self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
                                                            b["x"].data_ptr(), b["y"].data_ptr(), None, None, b["angle_dx"].data_ptr(), st))
-            elif s.kind == "dpole":
-                self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
-                                                         s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(), st))
-                # angle_dx of the cap reads the mesh back: same stream, right behind it (the bipolar mesh kernel fuses its angle)
-                self._timed("angle_x", lambda: L.call("ogg_grid_metrics_midas_dev", b["n"], ni1, b["x"].data_ptr(), b["y"].data_ptr(),
-                                                      b["n"], 0, p.Re, 1, None, None, None, b["angle_dx"].data_ptr(), st))
+            elif s.kind == "dpole":   # mesh, unwrap and angle_dx in one launch (its look-back words: the head of the band's workspace)
+                self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_angle_ws_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
+                                                         s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(),
+                                                         b["angle_dx"].data_ptr(), b["ws"].data_ptr(), b["ws_mesh_bytes"], st))
 
     def exchange_halo(self):
         """First x/y row of the band above -> halo row of this band (MIDAS sub-grids only)."""
@@ -448,10 +461,12 @@ class Supergrid(object):
                                                                    b["ws_bytes"], st))
                     else:
                         j0 = s.row0 + b["lo"]
-                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_ws_dev", 4, p.Ni, s.Nj, p.lon0, s.lat0,
-                                                                 s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
-                                                                 b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
-                                                                 b["ws_bytes"], st))
+                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_form_ws_dev", p.dp_arc, 4, p.Ni, s.Nj, p.lon0,
+                                                                 s.lat0, s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
+                                                                 b["dy"].data_ptr() if b["n_cell"] else None,
+                                                                 b["area"].data_ptr() if b["n_cell"] else None,
+                                                                 b["ws"].data_ptr() + b["ws_mesh_bytes"],
+                                                                 b["ws_bytes"] - b["ws_mesh_bytes"], st))
 
     def step(self, time_kernels=False):
         """One full pass of the hot path for this rank's bands; outputs stay in HBM."""
@@ -459,34 +474,15 @@ class Supergrid(object):
         self.run_pass()
 
     def run_pass(self):
-        """Phases A and B.  In fused mode the sub-grids are independent, so the caps run on two side streams next to the
-        lat-lon sub-grids (the HBM-bound lat-lon kernel overlaps the VALU-bound quadratures); everything joins back on
-        the caller's stream before returning.  Under graph capture this becomes a forked graph."""
+        """Phases A and B.  launch == "pass": everything through ogg_supergrid_pass_dev, on the caller's stream.  launch == "kernels":
+        one call per sub-grid and phase; with `overlap` the caps run on side streams next to the lat-lon sub-grids (the HBM-bound
+        lat-lon kernel overlaps the VALU-bound quadratures) and everything joins back on the caller's stream before returning
+        (under graph capture this becomes a forked graph)."""
         torch = self.torch
         if self.latlon == "fused" and self.launch == "pass":
-            dp = [s for s in self.plan.subs if s.kind == "dpole" and self.buf[s.name]["n"] > 0]
-            side = None
-            if dp and self.overlap and self.device.type == "cuda":  # the displaced-pole cap next to the pass, on one side stream
-                main = torch.cuda.current_stream(self.device)
-                if not self._side:
-                    self._side = [torch.cuda.Stream(self.device)]
-                side = self._side[0]
-                fork = torch.cuda.Event()
-                fork.record(main)
-                side.wait_event(fork)
-                with torch.cuda.stream(side):
-                    self.phase_a(kinds=("dpole",))
-                    self.phase_b(kinds=("dpole",))
-                    join = torch.cuda.Event()
-                    join.record(side)
             self.tripolar_pass()
             if self.plan.skip_metrics:
-                self.phase_b(kinds=("mercator", "latlon", "bipolar"))  # the -1 fill of OGG:1327-1329
-            if side is not None:
-                main.wait_event(join)
-            elif dp:
-                self.phase_a(kinds=("dpole",))
-                self.phase_b(kinds=("dpole",))
+                self.phase_b()  # the -1 fill of OGG:1327-1329
             return
         if self.latlon != "fused" or self.device.type != "cuda" or not self.overlap:
             self.phase_a()

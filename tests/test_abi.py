@@ -42,13 +42,14 @@ def test_ctypes_table_covers_the_header():
 
 
 def test_descriptor_structs_have_the_c_layout():
-    """The ctypes mirrors of the two descriptor structs must have the size the compiler gives them (a silent mismatch would
+    """The ctypes mirrors of the three descriptor structs must have the size the compiler gives them (a silent mismatch would
     shift every pointer), and the pass validates its arguments before any device work."""
     from ocean_model_grid_generator_amd import _lib
     lib = _lib.load()
     assert lib.ogg_abi_sizeof(0) == ctypes.sizeof(_lib.LatlonBand)
     assert lib.ogg_abi_sizeof(1) == ctypes.sizeof(_lib.BipolarBand)
-    assert lib.ogg_abi_sizeof(2) == -1
+    assert lib.ogg_abi_sizeof(2) == ctypes.sizeof(_lib.DpoleBand)
+    assert lib.ogg_abi_sizeof(3) == -1
     bands = (_lib.LatlonBand * 5)()
     rc = lib.ogg_tripolar_pass_dev(5, bands, 1441, -300.0, 360.0, 6371e3, 1, None, None)     # more than 4 lat-lon bands
     assert rc == _lib.OGG_EARG and b"at most 4 bands" in lib.ogg_last_error()
@@ -57,6 +58,15 @@ def test_descriptor_structs_have_the_c_layout():
     cap.x = cap.y = cap.angle = cap.dx = cap.dy = cap.area = 8     # never dereferenced: validation comes first
     rc = lib.ogg_tripolar_pass_dev(0, bands, 1441, -300.0, 360.0, 6371e3, 1, ctypes.byref(cap), None)
     assert rc == _lib.OGG_EORDER and lib.ogg_last_error() == b"Uncoded order"
+    scap = _lib.DpoleBand()
+    scap.Ni, scap.Nj, scap.n_pt_rows, scap.n_cell_rows, scap.order, scap.arc_form = 1440, 10, 4, 4, 3, 0
+    scap.x = scap.y = scap.angle = scap.dx = scap.dy = scap.area = scap.workspace = 8
+    scap.workspace_bytes = 1 << 30
+    rc = lib.ogg_supergrid_pass_dev(0, bands, 1441, -300.0, 360.0, 6371e3, 1, None, ctypes.byref(scap), None, None, None)
+    assert rc == _lib.OGG_EORDER and lib.ogg_last_error() == b"order not coded"        # OGG:547
+    scap.order, scap.arc_form = 4, 7
+    rc = lib.ogg_supergrid_pass_dev(0, bands, 1441, -300.0, 360.0, 6371e3, 1, None, ctypes.byref(scap), None, None, None)
+    assert rc == _lib.OGG_EARG and b"arc_form" in lib.ogg_last_error()
 
 
 def test_argument_errors_use_reference_texts():

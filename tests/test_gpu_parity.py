@@ -437,14 +437,15 @@ rp = np.tan(0.5 * (90 - lat0) * orc.PI_180)
 got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
 want = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
 out["bp"] = [float(np.max(np.abs(g - w)[w != 0] / np.abs(w[w != 0]))) for g, w in zip(got, want)]
-got = ogg.displacedPoleCap_metrics_quad(4, 720, 70, -300.0, -78.0, 80.0, 0.2)
 want = orc.displacedPoleCap_metrics_quad(4, 720, 70, -300.0, -78.0, 80.0, 0.2)
-out["dp"] = [float(np.max(np.abs(g[36:] - w[36:]) / np.abs(w[36:]))) for g, w in zip(got, want)]
+for form in ("literal", "chord"):
+    got = ogg.displacedPoleCap_metrics_quad(4, 720, 70, -300.0, -78.0, 80.0, 0.2, arc_form=form)
+    out["dp_" + form] = [float(np.max(np.abs(g[36:] - w[36:]) / np.abs(w[36:]))) for g, w in zip(got, want)]
 print("RESULT " + json.dumps(out))
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"OGG_BP_GUARD_K": "0", "OGG_DP_LITERAL": "1"}])
+@pytest.mark.parametrize("env", [{}, {"OGG_BP_GUARD_K": "0"}])
 def test_literal_kernels_in_fresh_process(hip, env):
     import subprocess
     import sys
@@ -455,4 +456,4 @@ def test_literal_kernels_in_fresh_process(hip, env):
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
     record("literal_env_%d" % len(env), **{k: max(v) for k, v in res.items()})
-    assert max(res["bp"]) < 5e-14 and max(res["dp"]) < 5e-7
+    assert max(res["bp"]) < 5e-14 and max(res["dp_literal"]) < 2e-9 and max(res["dp_chord"]) < 2e-9
