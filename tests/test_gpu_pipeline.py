@@ -131,7 +131,7 @@ def test_tripolar_pass_argument_errors(sg):
     plan = sg.SupergridPlan(1.0)
     g = sg.Supergrid(plan, device="cuda:0")
     g.step()
-    bands, arr, cap = g._pass_args
+    bands, arr, cap, _ = g._pass_args
     st = torch.cuda.current_stream().cuda_stream
     bad = L.BipolarBand.from_buffer_copy(cap)
     bad.order = 7
