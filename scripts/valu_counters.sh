@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage (GPU box, repo root): scripts/valu_counters.sh <tag> <workload> [extra bench.py arguments]
+# VALU-side counters of every kernel of a bench run (the pass launches and the stand-alone kernels of its last, per-kernel pass),
+# three counter passes; prints one line per kernel: mean counter values per launch.
+tag=$1; wl=$2; shift; shift
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/valu_${tag}_${wl}; rm -rf $out; mkdir -p $out
+args="bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample-div 0 --self-check 0 --d2h 0 --launch pass $*"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/a -o a --output-format csv -- python3 $args > $out/a.log 2>&1 &&
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d $out/b -o b --output-format csv -- python3 $args > $out/b.log 2>&1 &&
+rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR -d $out/c -o c --output-format csv -- python3 $args > $out/c.log 2>&1
+python3 - <<PY > $out/summary.txt
+import csv, glob, collections, re
+tot = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in "abc":
+    for f in glob.glob("$out/%s/**/*counter_collection.csv" % d, recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = re.sub(r"\(anonymous namespace\)::|void |\(.*", "", r["Kernel_Name"])
+            tot[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(tot.items()):
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    if m.get("SQ_INSTS_VALU", 0) < 1e5:
+        continue
+    busy = m["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (m["GRBM_GUI_ACTIVE"] / 8) if m.get("GRBM_GUI_ACTIVE") else 0
+    print("%-48s launches=%d valu=%.4g trans64=%.4g busy=%.1f%% gui/xcd=%.4g waves=%d wavecyc=%.4g wait_any=%.4g wait_inst=%.4g salu=%.4g" % (
+        k[:48], len(v["SQ_INSTS_VALU"]), m["SQ_INSTS_VALU"], m.get("SQ_INSTS_VALU_TRANS_F64", 0), 100 * busy, m.get("GRBM_GUI_ACTIVE", 0) / 8,
+        m.get("SQ_WAVES", 0), m.get("SQ_WAVE_CYCLES", 0), m.get("SQ_WAIT_ANY", 0), m.get("SQ_WAIT_INST_ANY", 0), m.get("SQ_INSTS_SALU", 0)))
+PY
+cat $out/summary.txt

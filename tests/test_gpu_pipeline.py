@@ -352,31 +352,44 @@ def test_full_size_r8_pass_vs_oracle(sg):
 
 def test_full_size_r8_latdp_pass_vs_oracle(sg):
     """BASELINE config 4 (1/8 degree with the displaced south pole, --lat_dp -85.85) at full size against the oracle (the
-    oracle needs ~40 s for the cap's finite-difference quadrature)."""
+    oracle needs ~40 s for the cap's finite-difference quadrature), in BOTH arc forms of the cap's quadrature.  The differences
+    of the two forms from the oracle, and from each other, go to the parity report (bench.py quotes them from
+    profiles/dp_parity.json); the chord form must stay within 5e-9 of the oracle and of the literal form."""
     import torch
-    from test_gpu_parity import record
+    from test_gpu_parity import record, dp_quad_rel_tol
     flags = dict(lon_dp=80.0, lat_dp=-85.85)
-    plan = sg.SupergridPlan(8.0, **flags)
-    g = sg.Supergrid(plan, device="cuda:0")
-    g.step()
-    torch.cuda.synchronize()
-    got = sg.stitch(plan, [g.bands_to_host()])
-    del g
     want = orc.make_supergrid(8.0, skip_doughnut_rows=True, **flags)
-    nsc = plan.subs[0].nj1 - 1      # cell rows of the displaced-pole cap: finite-difference metrics, 5e-7 relative (test_gpu_parity)
-    assert plan.subs[0].kind == "dpole"
-    rep = {}
-    for f in FIELDS:
-        assert got[f].shape == want[f].shape, f
-    rep["y_max"] = float(np.abs(got["y"] - want["y"]).max())
-    d = np.abs(got["x"] - want["x"])
-    rep["x_max"] = float(np.minimum(d, np.abs(d - 360.0)).max())
-    assert rep["y_max"] < 1e-12 and rep["x_max"] < 2e-11
+    rep, caps = {}, {}
+    for form in ("literal", "chord"):
+        plan = sg.SupergridPlan(8.0, dp_arc=form, **flags)
+        g = sg.Supergrid(plan, device="cuda:0")
+        assert g.launch == "pass"
+        g.step()
+        torch.cuda.synchronize()
+        got = sg.stitch(plan, [g.bands_to_host()])
+        del g
+        nsc = plan.subs[0].nj1 - 1      # cell rows of the displaced-pole cap
+        assert plan.subs[0].kind == "dpole"
+        for f in FIELDS:
+            assert got[f].shape == want[f].shape, f
+        rep["y_max"] = float(np.abs(got["y"] - want["y"]).max())
+        d = np.abs(got["x"] - want["x"])
+        rep["x_max"] = float(np.minimum(d, np.abs(d - 360.0)).max())
+        assert rep["y_max"] < 1e-12 and rep["x_max"] < 2e-11
+        caps[form] = {f: got[f][:nsc] for f in ("dx", "dy", "area")}
+        for f in ("dx", "dy", "area"):
+            d = np.abs(got[f] - want[f])
+            rel = d / np.maximum(np.abs(want[f]), 1e-300)
+            rep["%s_cap_max_rel_%s" % (f, form)] = float(rel[:nsc][want[f][:nsc] != 0].max())
+            rep["%s_cap_max_abs_%s" % (f, form)] = float(d[:nsc].max())
+            rep[f + "_rest_max_rel"] = float(rel[nsc:][want[f][nsc:] != 0].max())
+        del got
     for f in ("dx", "dy", "area"):
-        d = np.abs(got[f] - want[f])
-        rel = d / np.maximum(np.abs(want[f]), 1e-300)
-        rep[f + "_cap_max_rel"] = float(rel[:nsc][want[f][:nsc] != 0].max())
-        rep[f + "_rest_max_rel"] = float(rel[nsc:][want[f][nsc:] != 0].max())
+        rep[f + "_cap_chord_vs_literal_max_rel"] = float((np.abs(caps["chord"][f] - caps["literal"][f]) / np.abs(caps["literal"][f])).max())
     record("full_r8_latdp_pass_vs_oracle", **rep)
+    tol = dp_quad_rel_tol(plan.Ni)   # 1.15e-8: 10x the measured difference of either form
     for f in ("dx", "dy", "area"):
-        assert rep[f + "_cap_max_rel"] < 5e-7 and rep[f + "_rest_max_rel"] < 5e-12, (f, rep)
+        for form in ("literal", "chord"):
+            assert rep["%s_cap_max_rel_%s" % (f, form)] < min(tol, 5e-9 if form == "chord" else tol), (f, form, rep)
+        assert rep[f + "_cap_chord_vs_literal_max_rel"] < 5e-9, (f, rep)
+        assert rep[f + "_rest_max_rel"] < 5e-12, (f, rep)
