@@ -304,6 +304,9 @@ int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1
  * Device utilities used by the band-sharded pipeline (bench / multi-GPU)
  * ---------------------------------------------------------------------------------------------------- */
 int ogg_fill_dev(long n, double value, double* out, void* stream);
+/* Byte-swap-on-copy for write_nc's big-endian output (NetCDF classic, OGG:773-829): dst[k] = bswap64(src[k]), k < n.  src is device
+ * memory; dst is device memory or pinned host memory (hipHostMalloc / torch pin_memory), into which the kernel stores directly. */
+int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream);
 /* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:
  * out5 = { sum(area), sum(dy[:, col_a]), sum(dy[:, col_b]) (0 when col_b < 0), sum(dx[0, :]) if want_first_row,
  * sum(dx[n_dx_rows-1, :]) if want_last_row }.  dx: n_dx_rows x ni, dy: n_cell_rows x (ni+1), area: n_cell_rows x ni; out5 is a

@@ -38,10 +38,29 @@ __global__ void haversine_kernel(long n, const double* __restrict__ lam0d, const
     out[k] = 2.0 * asin(sqrt(d));
 }
 
+// write_nc's output is NetCDF classic (OGG:773-829): big-endian fp64.  Byte-swap-on-copy: 8-byte reversal of n values from device
+// memory into dst, which may be device memory or PINNED HOST memory (hipHostMalloc: mapped into the device's address space, so the
+// kernel's stores go straight over PCIe into the buffer the file is written from).  Grid-stride, one value per thread per step
+// (src and dst rows are only 8-byte aligned); 16 B of traffic per value.
+__global__ __launch_bounds__(256) void bswap64_kernel(long n, const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) dst[k] = __builtin_bswap64(src[k]);
+}
+
 inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 extern "C" {
+
+int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream) {
+    OGG_REQUIRE(n >= 0 && src && dst, OGG_EARG, "ogg_bswap64: bad argument");
+    if (n == 0) return OGG_OK;
+    const long blocks = (n + 255) / 256;
+    bswap64_kernel<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, ogg::as_stream(stream)>>>(
+        n, static_cast<const unsigned long long*>(src), static_cast<unsigned long long*>(dst));
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
 
 int ogg_mdist_dev(long n, const double* x1, const double* x2, double* out, void* stream) {
     OGG_REQUIRE(n >= 0 && x1 && x2 && out, OGG_EARG, "ogg_mdist: bad argument");

@@ -255,7 +255,8 @@ def _enhance_equator(phi_M, phi_n, refineR, enhanced_equatorial):
     return sym[0:j_phi_n]
 
 
-def mercator_axis(Ni, phi_s, phi_n, refineR, shift_equator_to_u_point=True, ensure_nj_even=True, enhanced_equatorial=0):
+def mercator_axis(Ni, phi_s, phi_n, refineR, shift_equator_to_u_point=True, ensure_nj_even=True, enhanced_equatorial=0,
+                  return_y_star=False):
     """1-D latitude axis of the Mercator sub-grid (OGG:316-428): device kernels for y* and phi, host parity logic."""
     print("Requesting Mercator grid with phi range: phi_s,phi_n=", phi_s, phi_n)
     y_star = y_mercator_rounded(Ni, np.array([phi_s * PI_180, phi_n * PI_180]))
@@ -282,6 +283,8 @@ def mercator_axis(Ni, phi_s, phi_n, refineR, shift_equator_to_u_point=True, ensu
         print("  *Equator is not going to be a u-point of this grid patch.")
     if enhanced_equatorial:
         phi_M = _enhance_equator(phi_M, phi_n, refineR, enhanced_equatorial)
+    if return_y_star:
+        return phi_M, y_star
     return phi_M
 
 
@@ -404,67 +407,6 @@ def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_d
     L.call("ogg_displaced_pole_metrics_quad_form", form, int(order), nx, ny, float(lon0), float(lat0), float(lon_dp), float(r_dp),
            float(Re), L.ptr(dxq), L.ptr(dyq), L.ptr(daq))
     return dxq, dyq, daq
-
-
-# ----------------------------------------------------------------------------------------------------------------
-# plotting helpers (host, matplotlib; OGG:604-679)
-# ----------------------------------------------------------------------------------------------------------------
-def cut_below(lam, phi, lowerlat):
-    jmin = 0
-    for jmin in range(0, lam.shape[0]):
-        if phi[jmin, 0] > lowerlat:
-            break
-    return lam[jmin:, :], phi[jmin:, :]
-
-
-def cut_above(lam, phi, upperlat):
-    jmax = 0
-    for jmax in range(0, lam.shape[0]):
-        if phi[jmax, 0] > upperlat:
-            break
-    return lam[0:jmax, :], phi[0:jmax, :]
-
-
-def plot_mesh_in_latlon(lam, phi, stride=1, phi_color="k", lam_color="r", newfig=True, title=None, axis=None, block=False):
-    import matplotlib.pyplot as plt
-
-    if phi.shape != lam.shape:
-        raise Exception("Ooops: lam and phi should have same shape")
-    nj, ni = lam.shape
-    if newfig:
-        plt.figure(figsize=(10, 10))
-    target = plt if axis is None else axis
-    for i in range(0, ni, stride):
-        target.plot(lam[:, i], phi[:, i], lam_color)
-    for j in range(0, nj, stride):
-        target.plot(lam[j, :], phi[j, :], phi_color)
-    if title is not None:
-        plt.title(title)
-    if not block:
-        plt.show()
-
-
-def plot_mesh_in_xyz(lam, phi, stride=1, phi_color="k", lam_color="r", lowerlat=None, upperlat=None, newfig=True, title=None,
-                     axis=None, block=False):
-    if lowerlat is not None:
-        lam, phi = cut_below(lam, phi, lowerlat=lowerlat)
-    if upperlat is not None:
-        lam, phi = cut_above(lam, phi, upperlat=upperlat)
-    x = np.cos(phi * PI_180) * np.cos(lam * PI_180)
-    y = np.cos(phi * PI_180) * np.sin(lam * PI_180)
-    plot_mesh_in_latlon(x, y, stride=stride, phi_color=phi_color, lam_color=lam_color, newfig=newfig, title=title, axis=None,
-                        block=False)
-
-
-def displacedPoleCap_plot(x_s, y_s, lon0, lon_dp, lat0, stride=40, block=False, dplat=None):
-    import matplotlib.pyplot as plt
-
-    plt.figure(figsize=(10, 10))
-    ax = plt.axes(projection="polar")
-    plot_mesh_in_latlon(x_s, y_s, stride=stride, newfig=False, axis=ax, block=block)
-    if dplat is not None:
-        ax.plot(lon_dp, dplat, color="r", marker="*")
-    return ax
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -630,15 +572,136 @@ def _script_metadata():
     return host, scriptpath, githash, gitmod
 
 
+def _validate_flags(match_dy, r_dp, lat_dp):
+    """OGG:881-888, 904-907"""
+    known_options = ["bp", "so", "p125sc", ""]
+    unknown = list(set(match_dy).difference(known_options))
+    if len(unknown) != 0:
+        print("Unknown options in match_dy: ", unknown)
+        print("Known options are one or more of ", known_options)
+        sys.exit(2)
+    if r_dp != 0.0 and lat_dp > -90.0:
+        print("Cannot specify both --rdp and --latdp for the displaced pole!")
+        usage()
+        sys.exit(2)
+
+
+def _meta_strings(inverse_resolution, no_changing_meta):
+    """history / source / description heads of OGG:946-963"""
+    hist = "This grid file was generated via command " + " ".join(sys.argv)
+    source = ""
+    if not no_changing_meta:
+        host, scriptpath, githash, gitmod = _script_metadata()
+        hist = hist + " on " + str(datetime.date.today()) + " on platform " + host
+        source = scriptpath + " had git hash " + githash + gitmod
+        source = source + ". To obtain the grid generating code do: git clone  https://github.com/nikizadehgfdl/grid_generation.git ; cd grid_generation;  git checkout " + githash
+    desc = ("This is an orthogonal coordinate grid for the Earth with a nominal resoution of " + str(1 / inverse_resolution)
+            + " degrees along the equator. ")
+    return hist, source, desc
+
+
 def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=None,
          south_cutoff_row=0, south_cutoff_ang=-90.0, reproduce_MIDAS_grids=False, write_subgrid_files=False, plotem=False,
          no_changing_meta=False, enhanced_equatorial=0, debug=False, grids="all", match_dy=(), skip_metrics=False,
          ensure_nj_even=False, shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0,
          mercator_upper_lat=-99.0, south_ocean_lower_lat=-99.0, south_ocean_upper_lat=-99.0, no_south_cap=False,
-         return_arrays=False):
-    """Build the supergrid and write it.  Same flags as the reference's main(); the defaults of ``grids`` and
-    ``match_dy`` are the argparse defaults (the reference's own function defaults fail its own validation,
-    OGG:870-888).  ``return_arrays=True`` additionally returns the six stitched fields (used by tests)."""
+         return_arrays=False, path=None, dp_arc=None):
+    """Build the supergrid and write it.  Same flags as the reference's main() (OGG:855-1449); the defaults of ``grids`` and
+    ``match_dy`` are the argparse defaults (the reference's own function defaults fail its own validation, OGG:870-888).
+
+    The sub-grid loop runs as ONE device-resident pass (supergrid.SupergridPlan + ogg_supergrid_pass_dev: three or four launches
+    for the whole grid, all six fields of every sub-grid left in HBM); the fields then go from HBM straight into the NetCDF file
+    (nc_stream: byte-swap-on-copy into a pinned ring, pwrite at each variable's offset) -- no per-function staging, no host
+    stitching.  ``path="functions"`` (or OGG_MAIN_PATH=functions) runs the reference's own sequence of calls instead, one host-array
+    function after the other (main_function_level): the same bits, for checking.  ``dp_arc`` (or OGG_DP_ARC): arc form of the
+    displaced-pole quadrature, "literal" (default) or "chord".  ``return_arrays=True`` additionally returns the six stitched
+    fields and the sub-grid pieces (used by tests)."""
+    import time
+
+    path = path or os.environ.get("OGG_MAIN_PATH", "pass")
+    dp_arc = dp_arc or os.environ.get("OGG_DP_ARC", "literal")
+    if path == "functions":
+        return main_function_level(inverse_resolution, gridfilename, r_dp, lon_dp, lat_dp, exfracdp, south_cutoff_row, south_cutoff_ang,
+                                   reproduce_MIDAS_grids, write_subgrid_files, plotem, no_changing_meta, enhanced_equatorial, debug, grids,
+                                   match_dy, skip_metrics, ensure_nj_even, shift_equator_to_u_point, bipolar_lower_lat, mercator_lower_lat,
+                                   mercator_upper_lat, south_ocean_lower_lat, south_ocean_upper_lat, no_south_cap, return_arrays, dp_arc)
+    from . import supergrid as SG
+
+    _validate_flags(match_dy, r_dp, lat_dp)
+    hist, source, desc = _meta_strings(inverse_resolution, no_changing_meta)
+    start_time = time.time()
+    plan = SG.SupergridPlan(inverse_resolution, r_dp=r_dp, lon_dp=lon_dp, lat_dp=lat_dp, exfracdp=exfracdp, south_cutoff_row=south_cutoff_row,
+                            south_cutoff_ang=south_cutoff_ang, skip_metrics=skip_metrics, ensure_nj_even=ensure_nj_even,
+                            no_south_cap=no_south_cap, enhanced_equatorial=enhanced_equatorial, match_dy=match_dy, grids=grids,
+                            shift_equator_to_u_point=shift_equator_to_u_point, bipolar_lower_lat=bipolar_lower_lat,
+                            mercator_lower_lat=mercator_lower_lat, mercator_upper_lat=mercator_upper_lat,
+                            south_ocean_lower_lat=south_ocean_lower_lat, dp_arc=dp_arc)
+    import torch
+    g = SG.Supergrid(plan, device="cuda:%d" % torch.cuda.current_device())
+    for s in plan.subs:
+        print("Generating %s sub-grid: %d rows x %d columns" % (s.name, s.nj1, plan.Ni + 1))
+    g.run_pass()
+    if not skip_metrics:   # the reference's CHECK_metrics lines (OGG:1017,1070,1112,1157,1172) from sums taken on the device
+        labels = {"Merc": "CHECK_metrics: % errors in (area, lat arc, lon arc)", "BP": "CHECK_metrics_hquad: % errors in (area, lat arc, lon arc1, lon arc2)",
+                  "SO": "CHECK_metrics_MIDAS: % errors in (area, lat arc, lon arc)"}
+        errs = g.metrics_error()
+        for name in ("Merc", "BP", "SO", "SC"):
+            if name in errs:
+                sc_dp = name == "SC" and plan.subs[0].kind == "dpole"
+                print("   " + labels.get(name, "CHECK_metrics_hquad: % errors in (area, lat arc, lon arc)" if sc_dp else labels["SO"]), errs[name])
+    # south cuts (OGG:1268-1313) and the final guards (OGG:1371-1375, 1425-1436) need two columns of y only
+    cut = g.south_cut()
+    print("Stitching the grids together...")
+    SG.check_guards(g.stitched_column("y", plan.Ni // 4, cut), any(s.name == "BP" for s in plan.subs))
+    names = [s.name for s in plan.subs if not (s.name == "SC" and cut[2])]
+    desc = desc + "It consists of; "
+    merc = next((s for s in plan.subs if s.name == "Merc"), None)
+    if merc is not None:
+        ym = g.stitched_column("y", 0, (0, 0, False), only="Merc")
+        desc = desc + "a Mercator grid spanning " + str(ym[0]) + " to " + str(ym[-1]) + " degrees; "
+        if "BP" in names:
+            desc = desc + "a bipolar northern cap north of " + str(ym[-1]) + " degrees; "
+    if "SO" in names:
+        desc = desc + "a regular lat-lon grid spanning " + str(plan.latUp_SO) + " to " + str(plan.lat0_SO) + " degrees; "
+    if "SC" in names:
+        desc = desc + "a " + ("displaced pole " if r_dp != 0.0 else "regular ") + "southern cap south of " + str(plan.lat0_SO) + " degrees."
+    if south_cutoff_ang > -90:
+        desc = desc + " It is cut south of " + str(south_cutoff_ang) + " degrees."
+    if south_cutoff_row > 0:
+        desc = desc + " The first " + str(south_cutoff_row) + " rows at south are deleted."
+    nyp = g.stitched_rows(cut)
+    print("shapes: ", (nyp, plan.Ni + 1), (nyp, plan.Ni + 1), (nyp, plan.Ni), (nyp - 1, plan.Ni + 1), (nyp - 1, plan.Ni), (nyp, plan.Ni + 1))
+    out = None
+    if return_arrays or write_subgrid_files or debug:
+        out = SG.stitch(plan, [g.bands_to_host()])
+    if write_subgrid_files:
+        for name, piece in out["sub"].items():
+            write_nc(piece["x"], piece["y"], piece["dx"], piece["dy"], piece["area"], piece["angle_dx"], axis_units="degrees",
+                     fnam=gridfilename + name + ".nc", description=desc, history=hist, source=source, debug=debug)
+        if "SC" not in out["sub"] and plan.Nj_scap != 0:
+            print("There remained no South Pole cap grid because of the number of rows cut= ", cut)
+    if gridfilename is not None:
+        if debug:
+            for lbl in ("x", "y", "dx", "dy", "area", "angle_dx"):
+                chksum(out[lbl], lbl)
+        g.write_nc(str(gridfilename), cut, description=desc, history=hist, source=source, no_changing_meta=no_changing_meta)
+        print("Wrote the whole grid to file ", gridfilename)
+    if plotem:
+        print("   --plotem: plotting (matplotlib, OGG:604-679) is not part of this build; the flag is accepted and ignored")
+    print("runtime(secs)  %s" % (time.time() - start_time))
+    if return_arrays:
+        return out
+
+
+def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=None,
+                        south_cutoff_row=0, south_cutoff_ang=-90.0, reproduce_MIDAS_grids=False, write_subgrid_files=False, plotem=False,
+                        no_changing_meta=False, enhanced_equatorial=0, debug=False, grids="all", match_dy=(), skip_metrics=False,
+                        ensure_nj_even=False, shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0,
+                        mercator_upper_lat=-99.0, south_ocean_lower_lat=-99.0, south_ocean_upper_lat=-99.0, no_south_cap=False,
+                        return_arrays=False, dp_arc="literal"):
+    """The reference's own sequence of calls (OGG:855-1449), every callee a host-array function of this module (numpy in, numpy
+    out, one staged device call each) and the stitching on the host: what a user gets who swaps the reference's module for this
+    one function by function.  main() produces the same bits from one device-resident pass."""
     import time
 
     known_options = ["bp", "so", "p125sc", ""]
@@ -784,7 +847,7 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
             angleSC = angle_x(lamSC, phiSC)
             dxSC, dySC, areaSC = _minus_ones(lamSC)
             if calculate_metrics:
-                dxSC, dySC, areaSC = displacedPoleCap_metrics_quad(4, Ni, Nj_scap, lon0, lat0_SC, lon_dp, r_dp)
+                dxSC, dySC, areaSC = displacedPoleCap_metrics_quad(4, Ni, Nj_scap, lon0, lat0_SC, lon_dp, r_dp, arc_form=dp_arc)
                 poles_i = int(Ni * np.mod(lon_dp - lon0, 360) / 360.0)
                 print("   CHECK_metrics_hquad: % errors in (area, lat arc, lon arc)",
                       metrics_error(dxSC, dySC, areaSC, Ni, lat1=lat0_SC, lat2=-90.0, displaced_pole=poles_i,
@@ -800,10 +863,6 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
             print("   number of js=", pieces[0].shape[0])
         sub["SC"] = pieces
         nc(sub["SC"], "SC")
-        if plotem:
-            ax = displacedPoleCap_plot(pieces[0], pieces[1], lon0, lon_dp, lat0_SC, stride=int(refineR * 10), block=True, dplat=lat_dp)
-            if "SO" in sub:
-                plot_mesh_in_latlon(sub["SO"][0], sub["SO"][1], stride=int(refineR * 10), newfig=False, axis=ax)
 
     # ---- south cuts (OGG:1268-1313)
     cut, jcut = False, 0
@@ -892,8 +951,7 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
                  source=source, no_changing_meta=no_changing_meta, debug=debug)
         print("Wrote the whole grid to file ", gridfilename)
     if plotem:
-        plot_mesh_in_xyz(x3, y3, stride=30, upperlat=-40, title="Grid south of -40 degrees")
-        plot_mesh_in_xyz(x3, y3, stride=30, lowerlat=40, title="Grid north of 40 degrees")
+        print("   --plotem: plotting (matplotlib, OGG:604-679) is not part of this build; the flag is accepted and ignored")
     print("runtime(secs)  %s" % (time.time() - start_time))
     if return_arrays:
         return {"x": x3, "y": y3, "dx": dx3, "dy": dy3, "area": area3, "angle_dx": angle3, "sub": sub}

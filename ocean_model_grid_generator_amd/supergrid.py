@@ -63,79 +63,127 @@ class SubGridPlan(object):
 
 
 class SupergridPlan(object):
-    """Host-side size logic of main() (OGG:969-1197) for the configurations the pipeline supports (no
-    enhanced_equatorial, no match_dy; south cuts are applied at stitch time).  Needs the GPU: y* and the joint
-    latitudes are read back from device-computed values, exactly as main() reads them from phiMerc."""
+    """Host-side size logic of main() (OGG:969-1197, 1268-1313) for its whole flag surface: sub-grid selection (--grids), latitude
+    overrides, --enhanced_equatorial (the spliced 1-D axis is built on the host, OGG:349-428, and handed to the lat-lon kernel as an
+    explicit axis), --match_dy, --ensure_nj_even, the displaced pole, the doughnut and the south cuts (applied at stitch time).
+    Needs the GPU unless ``mercator_axis`` is given: y* and the Mercator axis come from the device kernels, exactly as main() reads
+    the joint latitudes off phiMerc."""
 
-    def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0,
-                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, Re=ogg._default_Re, mercator_axis=None, dp_arc="literal"):
+    def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0, south_cutoff_ang=-90.0,
+                 skip_metrics=False, ensure_nj_even=False, no_south_cap=False, enhanced_equatorial=0, match_dy=(), grids="all",
+                 shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0, mercator_upper_lat=-99.0,
+                 south_ocean_lower_lat=-99.0, Re=ogg._default_Re, mercator_axis=None, dp_arc="literal"):
         """``mercator_axis`` = (y0, phi_M) lets a caller that already holds the Mercator ordinate range and axis skip the
         two device calls (the CPU tests of the band / halo logic pass values computed elsewhere).  ``dp_arc``: arc form of
-        the displaced-pole quadrature, "literal" (the reference's arithmetic) or "chord" (include/ogg_hip.h)."""
+        the displaced-pole quadrature, "literal" (the reference's arithmetic) or "chord" (include/ogg_hip.h).  ``exfracdp=None``:
+        main()'s own default 0.28*7/4 (OGG:891-892)."""
+        import contextlib
+        import io
+
         refineS, refineR = 2, inverse_resolution
         self.Re = Re
         self.dp_arc = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[dp_arc]
         self.skip_metrics = skip_metrics
-        self.south_cutoff_row = south_cutoff_row
+        self.ensure_nj_even = ensure_nj_even
+        self.south_cutoff_row, self.south_cutoff_ang = south_cutoff_row, south_cutoff_ang
         self.lon0, self.lenlon = -300.0, 360.0
         self.Ni = Ni = int(refineR * refineS * 360)
-        q = Ni // 4
+        doughnut = exfracdp if exfracdp is not None else 0.28 * 7 / 4
+
+        def want(tok):   # OGG:1003,1035,1100,1140
+            return (tok in grids) or ("all" in grids)
+
+        # ---- Mercator (OGG:987-1030)
         phi_s, phi_n = -66.85954725, 64.05895973
+        if mercator_upper_lat > -90:
+            phi_n = mercator_upper_lat
+        if mercator_lower_lat > -90:
+            phi_s = mercator_lower_lat
         if refineR == 2:
             phi_s, phi_n = -68.0, 65.0
-        # Mercator ordinate range: device y_mercator_rounded + host parity fixes (OGG:318-334)
-        if mercator_axis is None:
-            ys = ogg.y_mercator_rounded(Ni, np.array([phi_s * ogg.PI_180, phi_n * ogg.PI_180]))
-            y0, y1 = int(ys[0]), int(ys[1])
-            if y0 % 2 == 0:
-                y0, y1 = y0 - 1, y1 - 1
-            if (y1 - y0 + 1) % 2 == 0 and ensure_nj_even:
-                y1 -= 1
-            phi_M = ogg.phi_mercator(Ni, np.arange(y0, y1 + 1))
-        else:
-            y0, phi_M = int(mercator_axis[0]), np.asarray(mercator_axis[1], dtype=np.float64)
-        if np.searchsorted(phi_M, 0.0) == 0:
-            raise Exception("   Ooops: Equator is not in the grid")
-        skipM = 1 if (phi_M.size % 2 == 0 and ensure_nj_even) else 0
-        self.subs = []
-        merc = SubGridPlan("Merc", "mercator", phi_M.size - skipM, row0=skipM, y0=y0, n_axis=phi_M.size)
-        lat0_bp = float(phi_M[-1])
-        latUp_SO = float(phi_M[skipM])
-        # bipolar cap (OGG:1042-1062)
-        Nj_ncap = int(60 * refineR * refineS)
-        if refineR == 2:
-            Nj_ncap = 119 * refineS
-        if Nj_ncap % 2 != 0 and ensure_nj_even:
-            Nj_ncap -= 1
-        bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=lat0_bp, lon_bp=self.lon0,
-                         rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
-        # Row cost for the band split of the cap, in units of a plain cell row.  The quadrature guards its algebraic per-point form
-        # near the two pole points (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K))
-        # carry the guard (1.3x a plain row), and the band that holds the last row also runs the tail launch (literal fix-up of the
-        # guarded cells + the j = ny row), a fixed cost worth ~30 plain rows whatever the resolution.  These weights equalise the
-        # measured per-rank times of the fused pass at 1/8 and 1/16 degree over 2, 4 and 8 ranks (scripts/rank_sweep.py;
-        # OGG_BP_ROW_COST="fix,guard,lump" overrides them: weight of rows with fix-up cells, of guarded rows, lump on the last row).
-        import os
-        K = float(os.environ.get("OGG_BP_GUARD_K", "4000"))
-        if K > 4.0:
-            lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
-            guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
-            fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
-            w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,30").split(",")]
-            w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
-            bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
-            bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
-        # Southern Ocean (OGG:1080-1103)
+        if refineR == 1 and enhanced_equatorial:
+            phi_s, phi_n = -77.8, 60.0
+        merc = bp = so = sc = None
+        phi_kept = None   # the Mercator latitudes main() sees as phiMerc[:, Ni//4]
+        if want("mercator"):
+            if mercator_axis is None:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    phi_M, y_star = ogg.mercator_axis(Ni, phi_s, phi_n, refineR, shift_equator_to_u_point, ensure_nj_even, enhanced_equatorial,
+                                                      return_y_star=True)
+                y0 = int(y_star[0])
+            else:
+                y0, phi_M = int(mercator_axis[0]), np.asarray(mercator_axis[1], dtype=np.float64)
+                if np.searchsorted(phi_M, 0.0) == 0:
+                    raise Exception("   Ooops: Equator is not in the grid")
+            skipM = 1 if (phi_M.size % 2 == 0 and ensure_nj_even) else 0                     # OGG:434-437
+            merc = SubGridPlan("Merc", "mercator", phi_M.size - skipM, row0=skipM, y0=y0, n_axis=phi_M.size,
+                               explicit_axis=(np.ascontiguousarray(phi_M) if enhanced_equatorial else None))
+            phi_kept = phi_M[skipM:]
+            dphi_so, dphi_no = phi_kept[1] - phi_kept[0], phi_kept[-1] - phi_kept[-2]        # OGG:1024-1025
+            lat0_bp = float(phi_kept[-1])
+        # ---- bipolar cap (OGG:1035-1062)
+        if want("bipolar"):
+            if bipolar_lower_lat > -90:
+                lat0_bp = bipolar_lower_lat
+            elif merc is None:
+                raise Exception("the bipolar cap takes its lower latitude from the Mercator sub-grid (OGG:1030): add mercator to --grids "
+                                "or give --bipolar_lower_lat")
+            Nj_ncap = int(60 * refineR * refineS)
+            if refineR == 2:
+                Nj_ncap = 119 * refineS
+            if refineR == 1 and enhanced_equatorial:
+                Nj_ncap = 154
+            if "bp" in match_dy:
+                Nj_ncap = int(0.5 + (90.0 - lat0_bp) / dphi_no)
+            if Nj_ncap % 2 != 0 and ensure_nj_even:
+                Nj_ncap -= 1
+            bp = SubGridPlan("BP", "bipolar", Nj_ncap + 1, Nj=Nj_ncap, lat0_bp=float(lat0_bp), lon_bp=self.lon0,
+                             rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
+            # Row cost for the band split of the cap, in units of a plain cell row.  The quadrature guards its algebraic per-point form
+            # near the two pole points (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K))
+            # carry the guard (1.3x a plain row), and the band that holds the last row also runs the tail launch (literal fix-up of the
+            # guarded cells + the j = ny row), a fixed cost worth ~30 plain rows whatever the resolution.  These weights equalise the
+            # measured per-rank times of the fused pass at 1/8 and 1/16 degree over 2, 4 and 8 ranks (scripts/rank_sweep.py;
+            # OGG_BP_ROW_COST="fix,guard,lump" overrides them: weight of rows with fix-up cells, of guarded rows, lump on the last row).
+            import os
+            K = float(os.environ.get("OGG_BP_GUARD_K", "4000"))
+            if K > 4.0:
+                lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
+                guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
+                fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
+                w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,30").split(",")]
+                w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
+                bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
+                bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
+        # ---- Southern Ocean (OGG:1080-1103); like the reference this needs the Mercator sub-grid
         lat0_SO = -78.0
+        if south_ocean_lower_lat > -90:
+            lat0_SO = south_ocean_lower_lat
+        if phi_kept is None:
+            raise Exception("the Southern Ocean and southern cap sections read the Mercator sub-grid (OGG:1083): add mercator to --grids")
+        latUp_SO = float(phi_kept[0])
         lenlat_SO = latUp_SO - lat0_SO
         Nj_SO = int(refineR * 55)
-        skipS = 1 if ((Nj_SO + 1) % 2 == 0 and ensure_nj_even) else 0
-        so = SubGridPlan("SO", "latlon", Nj_SO + 1 - skipS, row0=skipS, lnj=Nj_SO, lat0=lat0_SO, lenlat=lenlat_SO)
-        # southern cap (OGG:1122-1197)
-        lat0_SC = lat0_SO + (skipS * lenlat_SO) / float(Nj_SO) if skipS else lat0_SO
+        if refineR == 2 and enhanced_equatorial:
+            Nj_SO = 109
+        if refineR == 1 and enhanced_equatorial:
+            Nj_SO = 0
+        if "so" in match_dy:
+            Nj_SO = int(0.5 + lenlat_SO / dphi_so)
+        skipS = 0
+        if Nj_SO != 0 and want("so"):
+            skipS = 1 if ((Nj_SO + 1) % 2 == 0 and ensure_nj_even) else 0
+            so = SubGridPlan("SO", "latlon", Nj_SO + 1 - skipS, row0=skipS, lnj=Nj_SO, lat0=lat0_SO, lenlat=lenlat_SO)
+        # ---- southern cap (OGG:1122-1197)
+        if so is None:
+            raise Exception("the southern cap section reads the Southern Ocean sub-grid (OGG:1122): it cannot be left out")
+        lat0_SC = lat0_SO + (skipS * lenlat_SO) / float(Nj_SO) if skipS else lat0_SO        # phiSO[0, Ni//4]
+        if "p125sc" in match_dy:
+            lat0_SC = lat0_SO
         Nj_scap = int(refineR * 40) * 7 // 4
-        sc = None
-        if not no_south_cap and Nj_scap != 0:
+        if no_south_cap or (enhanced_equatorial and refineR in (1, 2)):
+            Nj_scap = 0
+        if Nj_scap != 0 and want("sc"):
             if r_dp == 0.0 and lat_dp <= -90.0:
                 Nj_scap = int((lat0_SC + 90.0) / (1.0 / refineR / refineS))
                 skipC = 1 if ((Nj_scap + 1) % 2 == 0 and ensure_nj_even) else 0
@@ -144,25 +192,54 @@ class SupergridPlan(object):
                 if lat_dp > -90:
                     r_dp = float(np.tan((90 + lat_dp) * ogg.PI_180) / np.tan((90 + lat0_SC) * ogg.PI_180))
                 jmint = 0
-                if exfracdp != 0.0:
-                    jmin = np.ceil(exfracdp * Nj_scap)
+                if doughnut != 0.0:
+                    jmin = np.ceil(doughnut * Nj_scap)
                     jmint = int(jmin + np.mod(jmin, 2))
                 if (Nj_scap + 1 - jmint) % 2 == 0 and ensure_nj_even:
                     jmint += 1
                 sc = SubGridPlan("SC", "dpole", Nj_scap + 1 - jmint, row0=jmint, Nj=Nj_scap, lat0=lat0_SC, lon_dp=lon_dp, r_dp=r_dp)
+        self.Nj_scap = Nj_scap
+        self.lat0_SO, self.latUp_SO = lat0_SO, latUp_SO
         self.subs = [s for s in (sc, so, merc, bp) if s is not None]  # south -> north
 
-    def rows_cut(self):
-        """Rows removed at the south end of the stitched grid by --south_cutoff_row (OGG:1273-1313): jcut = n-1 rows
-        of the southern cap, or -- when that would consume the whole cap -- the cap and jcut - n_SC rows of the
-        Southern Ocean piece (which is one stitched row less, since stitching drops the cap's last row)."""
-        if self.south_cutoff_row <= 0:
-            return 0
-        jcut = self.south_cutoff_row - 1
+    def south_cut(self, sc_y0=None):
+        """(rows cut from the southern cap, rows cut from the Southern Ocean piece, cap removed) by --south_cutoff_row / _ang,
+        OGG:1268-1313, including the parity bumps of --ensure_nj_even.  ``sc_y0``: column 0 of the cap's latitudes, needed for
+        --south_cutoff_ang only."""
         first = self.subs[0]
-        if first.name == "SC" and jcut >= first.nj1:
-            return jcut - 1
-        return jcut
+        has_sc = first.name == "SC"
+        n_sc = first.nj1 if has_sc else 0
+        if self.south_cutoff_row > 0:
+            jcut = self.south_cutoff_row - 1
+        elif self.south_cutoff_ang > -90:
+            if not has_sc:
+                raise Exception("--south_cutoff_ang reads the southern cap's latitudes (OGG:1278): there is no southern cap")
+            if sc_y0 is None:
+                if first.kind != "latlon":
+                    raise ValueError("south_cut: the cap's latitudes are needed for --south_cutoff_ang")
+                sc_y0 = first.lat0 + (np.arange(first.row0, first.row0 + first.nj1) * first.lenlat) / float(first.lnj)
+            jcut = 1 + int(np.nonzero(np.asarray(sc_y0) < self.south_cutoff_ang)[0][-1])
+        else:
+            return 0, 0, False
+        if has_sc and jcut < n_sc:
+            if (n_sc - jcut) % 2 == 0 and self.ensure_nj_even:
+                jcut += 1
+            return jcut, 0, False
+        so = next((s for s in self.subs if s.name == "SO"), None)
+        if so is None:
+            return 0, 0, False
+        if not has_sc:
+            raise Exception("--south_cutoff_row without a southern cap: the reference reads lamSC here (OGG:1299)")
+        jcut_so = jcut - n_sc
+        if (so.nj1 - 1 - jcut_so - 1) % 2 == 0 and self.ensure_nj_even:
+            jcut_so += 1
+        return n_sc, jcut_so, True
+
+    def rows_cut(self, sc_y0=None):
+        """Rows removed at the south end of the stitched grid (stitching drops the cap's last row, so a cap that is cut away
+        altogether takes nj1 - 1 stitched rows with it)."""
+        c_sc, c_so, gone = self.south_cut(sc_y0)
+        return (self.subs[0].nj1 - 1 + c_so) if gone else c_sc
 
     @property
     def nyp(self):
@@ -219,7 +296,10 @@ class Supergrid(object):
                                   ("area", (b["n_cell"], ni1 - 1)), ("angle_dx", (n, ni1))):
                     b[f] = torch.empty((max(r, 0), c), dtype=torch.float64, device=self.device)
                 if s.kind == "mercator":
-                    b["axis"] = torch.empty(s.n_axis, dtype=torch.float64, device=self.device)
+                    if getattr(s, "explicit_axis", None) is not None:   # enhanced-equator axis: spliced on the host (OGG:349-428)
+                        b["axis"] = torch.from_numpy(s.explicit_axis).to(self.device)
+                    else:
+                        b["axis"] = torch.empty(s.n_axis, dtype=torch.float64, device=self.device)
                 elif s.kind == "latlon":
                     b["axis"] = torch.empty(s.lnj + 1, dtype=torch.float64, device=self.device)
                 elif s.kind == "bipolar":
@@ -274,7 +354,9 @@ class Supergrid(object):
             if b["n"] == 0 or not self._selected(s, only, kinds) or s.kind not in ("mercator", "latlon"):
                 continue
             band = L.LatlonBand()
-            if s.kind == "mercator":
+            if s.kind == "mercator" and getattr(s, "explicit_axis", None) is not None:
+                band.axis_kind, band.lat1d = 2, b["axis"].data_ptr()
+            elif s.kind == "mercator":
                 band.axis_kind, band.y0 = 1, s.y0
             else:
                 band.axis_kind, band.a0, band.len, band.denom = 0, s.lat0, s.lenlat, float(s.lnj)
@@ -381,7 +463,8 @@ class Supergrid(object):
                 if self.latlon == "fused":
                     continue
                 if s.kind == "mercator":
-                    L.call("ogg_mercator_axis_dev", p.Ni, s.y0, s.n_axis, b["axis"].data_ptr(), st)
+                    if getattr(s, "explicit_axis", None) is None:
+                        L.call("ogg_mercator_axis_dev", p.Ni, s.y0, s.n_axis, b["axis"].data_ptr(), st)
                 else:
                     L.call("ogg_linear_axis_dev", s.lnj + 1, s.lat0, s.lenlat, float(s.lnj), b["axis"].data_ptr(), st)
                 rows = b["n"] + (1 if (b["needs_halo"] and self.halo == "recompute") else 0)
@@ -599,6 +682,83 @@ class Supergrid(object):
         return out
 
     # -- results ---------------------------------------------------------------------------------------------
+    def south_cut(self):
+        """plan.south_cut() with the cap's latitudes read from the device when --south_cutoff_ang needs them (world 1)."""
+        first = self.plan.subs[0]
+        y0 = None
+        if first.name == "SC" and self.plan.south_cutoff_ang > -90 and self.plan.south_cutoff_row <= 0:
+            assert self.world == 1
+            y0 = self.buf["SC"]["y"][: self.buf["SC"]["n"], 0].cpu().numpy()
+        return self.plan.south_cut(y0)
+
+    def _pieces(self, cut, point_rows):
+        """[(sub-grid, first row, end row)] of a stitched field, south -> north (OGG:1315-1365): fields on point rows (x, y, dx,
+        angle_dx) drop the last row of every piece but the northernmost; dy and area (cell rows) are concatenated whole.  cut: the
+        triple of south_cut().  World 1 (the whole sub-grid is this rank's band)."""
+        assert self.world == 1
+        c_sc, c_so, gone = cut
+        subs = [s for s in self.plan.subs if not (s.name == "SC" and gone)]
+        out = []
+        for k, s in enumerate(subs):
+            b = self.buf[s.name]
+            lo = c_sc if s.name == "SC" else (c_so if (s.name == "SO" and gone) else 0)
+            if point_rows:
+                hi = b["n"] - (0 if k == len(subs) - 1 else 1)
+            else:
+                hi = b["n_cell"]
+            out.append((s, lo, max(hi, lo)))
+        return out
+
+    def stitched_rows(self, cut):
+        """nyp of the stitched grid"""
+        return sum(hi - lo for _, lo, hi in self._pieces(cut, True))
+
+    def stitched_column(self, field, col, cut, only=None):
+        """One column of a stitched field (or of one sub-grid) as a host array: what main()'s guards and description need."""
+        torch = self.torch
+        if only is not None:
+            b = self.buf[only]
+            return b[field][: b["n"], col].cpu().numpy()
+        parts = [self.buf[s.name][field][lo:hi, col] for s, lo, hi in self._pieces(cut, field in ("x", "y", "dx", "angle_dx"))]
+        return torch.cat(parts).cpu().numpy()
+
+    def write_nc(self, fnam, cut, description=None, history=None, source=None, no_changing_meta=None):
+        """write_nc of OGG:773-829 for the fields in HBM: the reference's layout (dimensions nyp, nxp, ny, nx, string(255); variables
+        tile, y, x, dy, dx, area, angle_dx in that order; NetCDF-3 64-bit offset), every band streamed from the device into its byte
+        range of the file (nc_stream).  Returns (bytes streamed, seconds)."""
+        import os
+        import time
+        from . import nc_stream, netcdf3
+        t0 = time.perf_counter()
+        nyp, nx = self.stitched_rows(cut), self.plan.Ni
+        ny = nyp - 1
+        print("   Writing netcdf file with ny,nx= ", ny, nx)
+        gatts = []
+        if not no_changing_meta:
+            gatts = [("history", history or ""), ("description", description or ""), ("source", source or "")]
+        ds = netcdf3.Dataset(fnam, [("nyp", nyp), ("nxp", nx + 1), ("ny", ny), ("nx", nx), ("string", 255)], gatts)
+        ds.decl_var("tile", netcdf3.NC_CHAR, ("string",), [])
+        spec = (("y", "y", ("nyp", "nxp"), "degrees"), ("x", "x", ("nyp", "nxp"), "degrees"), ("dy", "dy", ("ny", "nxp"), "meters"),
+                ("dx", "dx", ("nyp", "nx"), "meters"), ("area", "area", ("ny", "nx"), "m2"), ("angle_dx", "angle_dx", ("nyp", "nxp"), "degrees"))
+        for name, _, dims, units in spec:
+            ds.decl_var(name, netcdf3.NC_DOUBLE, dims, [("units", units)])
+        fd = os.open(fnam, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            ds.write_header(fd)
+            os.pwrite(fd, b"tile1".ljust(255, b"\0"), ds.var_begin("tile"))
+            stream = nc_stream.DeviceToFile(fd, self.device)
+            for name, f, _, _ in spec:
+                off = ds.var_begin(name)
+                for s, lo, hi in self._pieces(cut, f in ("x", "y", "dx", "angle_dx")):
+                    if hi > lo:
+                        t = self.buf[s.name][f][lo:hi]
+                        stream.put(t, off)
+                        off += t.numel() * 8
+            stream.finish()
+        finally:
+            os.close(fd)
+        return stream.bytes, time.perf_counter() - t0
+
     def bands_to_host(self):
         """This rank's bands as numpy arrays (halo rows dropped): {sub: {field: array}}."""
         out = {}
@@ -608,22 +768,43 @@ class Supergrid(object):
         return out
 
 
-def stitch(plan, per_rank_bands):
-    """Concatenate the bands of all ranks per sub-grid, then stitch the sub-grids south -> north as OGG:1315-1365
-    (x, y, dx, angle_dx drop the southern piece's last row; dy, area are concatenated whole), then apply
-    --south_cutoff_row."""
+def stitch(plan, per_rank_bands, guards=False):
+    """Concatenate the bands of all ranks per sub-grid, apply --south_cutoff_row / _ang to the southern pieces (OGG:1268-1313), then
+    stitch the sub-grids south -> north as OGG:1315-1365 (x, y, dx, angle_dx drop the southern piece's last row; dy, area are
+    concatenated whole).  ``guards``: raise like the reference on a grid it rejects (OGG:1371-1375, 1425-1436)."""
     subs = {}
     for s in plan.subs:
         subs[s.name] = {f: np.concatenate([bands[s.name][f] for bands in per_rank_bands], axis=0) for f in FIELDS}
+    c_sc, c_so, gone = plan.south_cut(subs["SC"]["y"][:, 0] if "SC" in subs else None)
+    if gone:
+        del subs["SC"]
+        subs["SO"] = {f: v[c_so:, :] for f, v in subs["SO"].items()}
+    elif c_sc > 0:
+        subs["SC"] = {f: v[c_sc:, :] for f, v in subs["SC"].items()}
     g = None
     for s in plan.subs:
+        if s.name not in subs:
+            continue
         piece = subs[s.name]
         if g is None:
             g = dict(piece)
         else:
             g = {f: np.concatenate((g[f] if f in ("dy", "area") else g[f][:-1, :], piece[f]), axis=0) for f in FIELDS}
-    jcut = plan.rows_cut()
-    if jcut > 0:
-        g = {f: g[f][jcut:, :] for f in FIELDS}
+    if guards:
+        check_guards(g["y"][:, plan.Ni // 4], "BP" in subs)
     g["sub"] = subs
     return g
+
+
+def check_guards(ycol, has_bp):
+    """The reference's final checks on column Ni//4 of the stitched latitudes (OGG:1371-1375, 1425-1436)."""
+    if has_bp and np.any((np.roll(ycol, shift=-1, axis=0) - ycol) == 0):
+        raise Exception("lattitude array has repeated values along symmetry meridian!")
+    equator_index = np.searchsorted(ycol, 0.0)
+    if equator_index == 0:
+        raise Exception("   Ooops: Equator is not in the grid")
+    print("   Equator is at j=", equator_index)
+    if equator_index % 2 == 0:
+        raise Exception("Ooops: Equator is not going to be a u-point. Use option --south_cutoff_row to one more or on less row from south.")
+    if ycol.shape[0] % 2 == 0:
+        raise Exception("Ooops: The number of j's in the supergrid is not even. Use option --south_cutoff_row to one more or on less row from south.")

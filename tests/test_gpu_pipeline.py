@@ -216,24 +216,78 @@ def test_more_ranks_than_rows(sg):
         assert np.array_equal(one[f], many[f]), f
 
 
-def test_pipeline_matches_main_bitwise(sg):
-    """The device-resident pass and the host-pointer drop-in functions run the same kernels."""
-    import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
-    plan = sg.SupergridPlan(1.0, south_cutoff_row=2)
-    got = run(sg, plan)
-    ref = ogg.main(1.0, gridfilename=None, south_cutoff_row=2, no_changing_meta=True, return_arrays=True)
+def _same_as_function_level(got, ref, name):
+    """Bit identity of the pass path with the function-level path, field by field; angle_dx on the bipolar cap excepted: the
+    function-level path applies the generic angle_x kernel to the stored mesh, the pass takes the cap's angle inside the mesh kernel
+    with cos(phi) in its algebraic form 2u/(1+u^2) -- < 1e-10 degrees apart away from the two pole points."""
     for f in FIELDS:
+        assert got[f].shape == ref[f].shape, (name, f, got[f].shape, ref[f].shape)
         if f != "angle_dx":
-            assert np.array_equal(got[f], ref[f]), f
-    # angle_dx: main() applies the generic angle_x kernel to the stored mesh, the pass takes the cap's angle inside the mesh
-    # kernel with cos(phi) in its algebraic form 2u/(1+u^2) -- same bits on the lat-lon sub-grids, < 1e-10 degrees on the cap
-    # away from the two pole points
-    bp0 = plan.nyp - plan.subs[-1].nj1
-    assert plan.subs[-1].kind == "bipolar"
-    assert np.array_equal(got["angle_dx"][:bp0], ref["angle_dx"][:bp0])
-    d = np.abs(got["angle_dx"][bp0:] - ref["angle_dx"][bp0:])
-    d = np.minimum(d, np.abs(d - 360.0))
-    assert np.quantile(d, 0.999) < 1e-10 and np.median(d) < 1e-12, (float(np.quantile(d, 0.999)), float(d.max()))
+            assert np.array_equal(got[f], ref[f]), (name, f)
+    nbp = got["sub"]["BP"]["x"].shape[0] if "BP" in got["sub"] else 0
+    n = got["angle_dx"].shape[0]
+    assert np.array_equal(got["angle_dx"][: n - nbp], ref["angle_dx"][: n - nbp]), name
+    if nbp:
+        d = np.abs(got["angle_dx"][n - nbp:] - ref["angle_dx"][n - nbp:])
+        d = np.minimum(d, np.abs(d - 360.0))
+        assert np.quantile(d, 0.999) < 1e-10 and np.median(d) < 1e-12, (name, float(np.quantile(d, 0.999)), float(d.max()))
+
+
+_GOLDEN_CONFIGS = sorted(json.load(open(os.path.join(GOLD, "ref_hashes.json")))["configs"])
+
+
+@pytest.mark.parametrize("name", _GOLDEN_CONFIGS)
+def test_main_pass_path_matches_function_level_path(hip, name, tmp_path):
+    """main() (one device-resident pass, fields streamed from HBM into the file) against main(path="functions") (the reference's own
+    sequence of host-array calls) on every golden configuration: the whole flag surface -- enhanced_equatorial (explicit axis,
+    axis_kind = 2), match_dy, south cuts by row and by angle, latitude overrides, no_south_cap, ensure_nj_even, both displaced-pole
+    spellings.  The file the pass path writes holds the same arrays."""
+    import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+    from scipy.io import netcdf_file
+    cfg = json.load(open(os.path.join(GOLD, "ref_hashes.json")))["configs"][name]
+    flags = dict(cfg["flags"])
+    out = str(tmp_path / "g.nc")
+    got = ogg.main(gridfilename=out, no_changing_meta=True, return_arrays=True, **flags)
+    for f, shp in cfg["shapes"].items():
+        assert list(got[f].shape) == shp, (f, got[f].shape, shp)          # shapes pinned by the reference run
+    ref = ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, path="functions", **flags)
+    ref = dict(ref, sub={k: dict(zip(FIELDS, v)) for k, v in ref["sub"].items()})
+    _same_as_function_level(got, ref, name)
+    nc = netcdf_file(out, "r", mmap=True)
+    assert list(nc.variables.keys()) == ["tile", "y", "x", "dy", "dx", "area", "angle_dx"] and nc.version_byte == 2
+    for f in FIELDS:
+        assert np.array_equal(nc.variables[f][:], got[f]), (name, f)
+    del f
+    nc.close()
+
+
+@pytest.mark.parametrize("flags", [
+    dict(inverse_resolution=1.0, ensure_nj_even=True, south_cutoff_row=2),      # the reference's own guard rejects the even one of
+    dict(inverse_resolution=1.0, ensure_nj_even=True, south_cutoff_row=3),      # these two (OGG:1434): both paths must agree
+    dict(inverse_resolution=1.0, ensure_nj_even=True, south_cutoff_row=30),     # consumes the whole southern cap and part of SO
+    dict(inverse_resolution=0.5, ensure_nj_even=True, r_dp=0.2, south_cutoff_row=4),
+    dict(inverse_resolution=0.5, ensure_nj_even=True, r_dp=0.2, south_cutoff_ang=-80.5),
+    dict(inverse_resolution=1.0, grids=["bipolar", "mercator", "so"]),
+    dict(inverse_resolution=0.5, bipolar_lower_lat=66.0, mercator_upper_lat=66.0, mercator_lower_lat=-65.0),
+])
+def test_plan_cuts_and_parity_bumps_follow_the_reference(sg, flags):
+    """SupergridPlan.south_cut / stitch against the oracle's restatement of OGG:1268-1313 incl. the --ensure_nj_even parity bumps
+    (SC: (n_SC - jcut) % 2 == 0 -> jcut += 1; SO: (n_cell_SO - jcut_SO - 1) % 2 == 0 -> jcut_SO += 1) and the final guards."""
+    import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+    flags = dict(flags)
+    r = flags.pop("inverse_resolution")
+    try:
+        want = orc.make_supergrid(r, skip_doughnut_rows=True, **flags)
+    except Exception as exc:   # the reference's own guards reject this flag set: ours must raise the same text
+        with pytest.raises(Exception) as ei:
+            ogg.main(r, gridfilename=None, no_changing_meta=True, return_arrays=True, **flags)
+        assert str(ei.value) == str(exc)
+        return
+    got = ogg.main(r, gridfilename=None, no_changing_meta=True, return_arrays=True, **flags)
+    plan = sg.SupergridPlan(r, **flags)
+    if flags.get("south_cutoff_ang", -90.0) <= -90.0:
+        assert plan.nyp == want["y"].shape[0]
+    _check_supergrid(got, want, "cuts_%s" % "_".join("%s" % v for v in flags.values()))
 
 
 def test_full_size_properties_r8(sg):
