@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="run the caps on side streams next to the lat-lon sub-grids")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph in the timed region (0: eager launches)")
     ap.add_argument("--d2h", type=int, default=1, help="after the timed region: time the copy of this rank's bands to pinned host memory (information)")
+    ap.add_argument("--checksum", type=int, default=1, help="after the timed region: 64-bit sums of the bit patterns of every field of every "
+                    "sub-grid, added over the ranks (one all-reduce): a band-sharded run must print the single-GPU values")
     ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
     ap.add_argument("--dp-arc", default="chord", choices=["chord", "literal"],
                     help="arc form of the displaced-pole quadrature (workloads with a displaced pole only): chord (same finite-difference "
@@ -272,6 +274,7 @@ def main():
             sg.run_pass()
     sync()
     dt = time.perf_counter() - t0
+    dt_local = dt
     launches = None
     if sample:
         sg.pass_events = events
@@ -290,6 +293,29 @@ def main():
                 self_check = {k: [None if e != e else float(e) for e in v] for k, v in sg.metrics_error().items()}  # NaN (not estimable) -> null
         except Exception as exc:  # never lose the bench line over the self-check
             self_check = {"error": repr(exc)}
+    # bit-level fingerprint of the result: per sub-grid and field the wrapping 64-bit sum of the values' bit patterns over this rank's
+    # band, added over the ranks -- independent of the band decomposition, so N ranks must reproduce the 1-GPU numbers exactly
+    checksums = None
+    if args.checksum and args.as_rank is None:
+        try:
+            cs = torch.zeros((len(plan.subs), len(supergrid.FIELDS)), dtype=torch.int64, device=device)
+            for a, s_ in enumerate(plan.subs):
+                b = sg.buf[s_.name]
+                for c, f in enumerate(supergrid.FIELDS):
+                    t = b[f][: b["n"]] if f in ("x", "y") else b[f]
+                    if t.numel():
+                        cs[a, c] = t.contiguous().view(torch.int64).sum()
+            if use_dist:
+                dist.all_reduce(cs)
+            checksums = {s_.name: {f: "%016x" % (int(cs[a, c].item()) & 0xFFFFFFFFFFFFFFFF) for c, f in enumerate(supergrid.FIELDS)}
+                         for a, s_ in enumerate(plan.subs)}
+        except Exception as exc:
+            checksums = {"error": repr(exc)}
+    per_rank = None
+    if use_dist:   # every rank's own time and launch scheme (rank 0 prints them)
+        mine = {"rank": rank, "ms_per_step": dt_local / args.steps * 1e3, "launch": "%s graph=%d" % (sg.launch, int(use_graph)), "device": local_rank}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     # for information (SURVEY 8d ii): this rank's bands copied to pinned host memory, after the pass
     d2h = None
     if args.d2h:
@@ -359,7 +385,7 @@ def main():
                             "kernel, the cap kernels are fp64-VALU bound (DESIGN.md 4)"}
         out = {
             "metric": METRIC, "value": plan.cells * args.steps / dt, "unit": "cells/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
@@ -370,7 +396,7 @@ def main():
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": roof, "pass_launches": launches,
             "parity": _dp_parity(args.dp_arc) if has_dp else None,
-            "self_check_metrics_error_percent": self_check,
+            "self_check_metrics_error_percent": self_check, "field_checksums": checksums,
             "d2h_pinned_after_pass": d2h,
             "kernels": kernels,
         }

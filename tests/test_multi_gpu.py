@@ -1,0 +1,64 @@
+"""Multi-GPU readiness: on a box with >= 2 visible GPUs, bench.py under torch.distributed.run with 2 ranks (RCCL) must reproduce
+the single-GPU result bit for bit -- for the default pipeline (fused pass, no data-path collective) and for the pipeline of
+BASELINE.json's north_star taken literally (tile, one-row halo over RCCL send/recv, generic stencil kernel).  Skips itself on a
+one-GPU box (the driver's 8-GPU node is the only place this runs for real).  The children are separate processes started from
+scratch (nothing is exec'ed from this process)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()   # does not initialise the GPU on this image
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench(n, extra):
+    args = ["bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1", "--cpu-sample-div", "0", "--d2h", "0", "--workload", "r2"] + extra
+    if n == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(_port())] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("extra", [[], ["--latlon", "stencil", "--halo", "rccl"]], ids=["fused_pass", "stencil_rccl_halo"])
+def test_two_ranks_reproduce_one_gpu_bitwise(extra):
+    if _gpus() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    one = _bench(1, [])
+    two = _bench(2, extra)
+    assert two["n_gpus"] == 2 and two["world_size"] == 2 and len(two["per_rank"]) == 2
+    assert two["field_checksums"] == one["field_checksums"], (one["field_checksums"], two["field_checksums"])
+    assert two["config"]["cells"] == one["config"]["cells"]
+
+
+def test_checksum_is_independent_of_the_pipeline():
+    """One GPU: the fused pass and the stencil pipeline print the same fingerprints (the property the 2-rank test relies on), and a
+    world-size-1 process group (RCCL init, barrier, all-reduce) leaves them unchanged."""
+    a = _bench(1, [])
+    b = _bench(1, ["--latlon", "stencil"])
+    assert a["field_checksums"] == b["field_checksums"] and "error" not in a["field_checksums"]
+    env = dict(os.environ, OGG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-sample-div", "0", "--d2h", "0", "--workload", "r2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    c = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert c["field_checksums"] == a["field_checksums"] and c["world_size"] == 1 and c["per_rank"][0]["rank"] == 0
