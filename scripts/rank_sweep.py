@@ -16,13 +16,15 @@ from ocean_model_grid_generator_amd import supergrid  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--workload", default="r8")
-ap.add_argument("--cost", nargs="*", default=["2.6,1.35"])
+ap.add_argument("--cost", nargs="*", default=["1.3,1.3,30"])
+ap.add_argument("--dp-arc", default="chord")
+ap.add_argument("--json", default=None, help="append one JSON line per (world, cost) to this file")
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--launch", default="pass")
 args = ap.parse_args()
 for cost in args.cost:
     os.environ["OGG_BP_ROW_COST"] = cost
-    plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
+    plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **bench.WORKLOADS[args.workload])
     ts = []
     for r in range(args.world):
         sg = supergrid.Supergrid(plan, rank=r, world=args.world, device="cuda:0", halo="recompute")
@@ -36,4 +38,11 @@ for cost in args.cost:
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / args.steps * 1e3)
         del sg
+    if args.json:
+        import json
+        with open(args.json, "a") as f:
+            f.write(json.dumps({"workload": args.workload, "dp_arc": args.dp_arc, "world": args.world, "row_cost": cost, "launch": args.launch,
+                                "steps": args.steps, "ms_per_rank": ts, "ms_slowest_rank": max(ts),
+                                "note": "each rank's share of the band split timed on ONE GPU, one after the other (rehearsal; no "
+                                        "multi-GPU hardware curve exists yet)"}) + "\n")
     print("world %d cost %s: max %.4f ms  [%s]" % (args.world, cost, max(ts), " ".join("%.4f" % t for t in ts)), flush=True)
