@@ -186,6 +186,35 @@ OGG_DEV unsigned lb_incoming(const unsigned long long* row_words, long s, unsign
     return t0 & all;
 }
 
+// The same for ONE scan (1-bit maps).  f(0) <= f(1) always (lowering the previous column can only raise the difference), so a map is
+// "constant 0", "constant 1" or the identity, and the state after a run of maps is the value of the LAST constant one: two ballots and
+// a count-leading-zeros instead of a 6-step shuffle scan.
+OGG_DEV unsigned lb_incoming1(const unsigned long long* row_words, long s, int* err) {
+    const int lane = threadIdx.x & 63;
+    unsigned st = 0u;
+    for (long base = 0; base < s; base += 64) {
+        const long k = base + lane;
+        const bool have = k < s;
+        unsigned long long w = LB_VALID | (1ull << 16);   // identity
+        int spins = 0;
+        for (;;) {
+            if (have) w = __hip_atomic_load(row_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot((w & LB_VALID) != 0ull) == ~0ull) break;
+            ++spins;
+            if (spins > LB_SPIN_LIMIT) {
+                if (lane == 0) atomicExch(err, 1);
+                break;
+            }
+            if ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const unsigned m0 = (unsigned)(w & 1ull), m1 = (unsigned)((w >> 16) & 1ull);
+        const unsigned long long C = __ballot(have && m0 == m1), V = __ballot(m0 != 0u);
+        if (C) st = (unsigned)((V >> (63 - __builtin_clzll(C))) & 1ull);
+    }
+    return st;
+}
+
 // work item of a workgroup from an atomic ticket (see the head of this file); one barrier
 OGG_DEV long take_ticket(unsigned* counter, unsigned* s_slot) {
     if (threadIdx.x == 0) *s_slot = atomicAdd(counter, 1u);
@@ -302,37 +331,52 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
 // ds is the haversine distance between two projected points that are ~2e-6 rad apart, formed from longitudes/latitudes in
 // degrees.  That subtraction of two O(1) angles loses 10 digits: against an 80-bit evaluation the reference's own h is
 // accurate to 2e-9 (relative).  The chord form keeps the SAME stencil (the same probe points, the same conformal image w of
-// each probe) but takes the distance between two probes from their positions on the sphere -- from the gnomonic images
-// pa, pb = (X, Y, -1): sin(ds) = |pa x pb| / (|pa| |pb|) -- : no atan2 / atan / hypot per probe, no sin/cos/asin per pair and
-// no longitude at all, hence no unwrap.  Its h is accurate to 8e-10 and differs from the reference's by ~1.6e-9, i.e. by less
+// each probe) but takes the distance between two probes from their positions on the sphere -- from vectors pa, pb along the two
+// points: sin(ds) = |pa x pb| / (|pa| |pb|) -- : no atan2 / atan / hypot per probe, no sin/cos/asin per pair and no longitude at
+// all, hence no unwrap.  Its h is accurate to 8e-10 and differs from the reference's by ~1.6e-9, i.e. by less
 // than the reference's own rounding error, but it is NOT the reference's arithmetic: it is an explicit option (arc_form = 1),
 // the literal form is the default everywhere.
-struct Gno {
-    double X, Y;   // gnomonic image (plane tangent at the south pole) of a point of the sphere
+// A probe's point on the sphere in homogeneous form: with w = num / den the conformal image of the probe (OGG:454-455),
+// (X, Y) = r_joint w its gnomonic image and (X, Y, -1) a vector along the point, so is
+//   (P, Q, -D) = (r_joint Re(num conj(den)), r_joint Im(num conj(den)), -|den|^2)
+// -- no division per probe.  num = r e' + z0 and den = 1 + r conj(z0) e' are each one fma per component.
+struct Hom {
+    double P, Q, D;
 };
 
-// w * r_joint, w the conformal image of the probe (OGG:454-455), with the complex quotient formed from one Newton reciprocal
-// of |den|^2 (<= 2 ulp): the point of the sphere is (X, Y, -1) / sqrt(1 + X^2 + Y^2).
-OGG_DEV Gno dp_gnomonic(double r, cplx ep, const DpConst& c) {
-    const double zr = r * ep.re, zi = r * ep.im;
-    const double nr = zr + c.z0r, ni = zi + c.z0i;
-    const double dr = 1 + fma(c.z0r, zr, c.z0i * zi);      // 1 + conj(z0) z
-    const double di = fma(c.z0r, zi, -(c.z0i * zr));
-    const double s = rcp_nr(fma(dr, dr, di * di)) * c.r_joint;
-    return Gno{fma(nr, dr, ni * di) * s, fma(ni, dr, -(nr * di)) * s};
+// (P, Q, -D) scaled by 1 / r_joint: (Re(num conj(den)), Im(num conj(den)), -|den|^2 / r_joint)
+OGG_DEV Hom dp_homogeneous(double r, cplx ep, const DpConst& c, double inv_rj) {
+    const double cr = fma(c.z0r, ep.re, c.z0i * ep.im), ci = fma(c.z0r, ep.im, -(c.z0i * ep.re));   // conj(z0) e' (column-only: hoisted)
+    const double nr = fma(r, ep.re, c.z0r), ni = fma(r, ep.im, c.z0i);
+    const double dr = fma(r, cr, 1.0), di = r * ci;
+    Hom h;
+    h.P = fma(nr, dr, ni * di);
+    h.Q = fma(ni, dr, -(nr * di));
+    h.D = fma(dr, dr, di * di) * inv_rj;
+    return h;
 }
 
-// Great-arc distance of two nearby points from their gnomonic images a, b: with p = (X, Y, -1),
-//   sin(theta) = |pa x pb| / (|pa| |pb|),   |pa x pb|^2 = dX^2 + dY^2 + (Xa dY - Ya dX)^2,   |p|^2 = 1 + X^2 + Y^2
-OGG_DEV double gnomonic_arc(const Gno& a, const Gno& b) {
-    const double dX = b.X - a.X, dY = b.Y - a.Y;
-    const double cr = fma(a.X, dY, -(a.Y * dX));
-    const double s2 = fma(dX, dX, fma(dY, dY, cr * cr));
-    if (s2 == 0.0) return 0.0;
-    const double na = fma(a.X, a.X, fma(a.Y, a.Y, 1.0)), nb = fma(b.X, b.X, fma(b.Y, b.Y, 1.0));
-    const double q = s2 * rcp_nr(na * nb);            // sin^2(theta)
-    const double sn = sqrt_nr(q);
-    return (sn < 1e-3) ? sn * (1.0 + q * (1.0 / 6.0 + q * (3.0 / 40.0))) : asin(sn);
+// Great-arc distance of two nearby points a, b given along (P, Q, -D): tan(theta) = |a x b| / (a . b); theta = atan(tan theta)
+// from three terms of the series (the probes of the eps = 1e-3 stencil are ~1e-6 rad apart; exact to 1e-30 below 1e-3).  One
+// reciprocal square root per arc, seed + one Newton step (2^-50: the cross product itself carries 1e-10 of cancellation):
+// tan theta = |a x b|^2 / sqrt(|a x b|^2 (a . b)^2).
+OGG_DEV double homogeneous_arc(const Hom& a, const Hom& b) {
+    const double c1 = fma(a.D, b.Q, -(a.Q * b.D));
+    const double c2 = fma(a.P, b.D, -(a.D * b.P));
+    const double c3 = fma(a.P, b.Q, -(a.Q * b.P));
+    const double cc = fma(c1, c1, fma(c2, c2, c3 * c3));
+    if (cc == 0.0) return 0.0;
+    const double dot = fma(a.P, b.P, fma(a.Q, b.Q, a.D * b.D));
+    const double x = cc * (dot * dot);
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    const double t = cc * y;                   // tan(theta)
+    const double q = t * t;
+    double th = t * fma(q, fma(q, 1.0 / 5.0, -1.0 / 3.0), 1.0);
+    // grids so coarse that two probes are more than 1e-3 rad apart (a few dozen columns): the whole wave takes the library atan, behind a
+    // wave-uniform branch that the fine grids never enter
+    if (__builtin_expect(__ballot(t >= 1e-3) != 0ull, 0)) th = (t >= 1e-3) ? atan(t) : th;
+    return th;
 }
 
 // -- one lattice row, one column per lane ---------------------------------------------------------------------------------
@@ -416,13 +460,14 @@ OGG_DEV void dq_literal_finish(const DqPending<F>& o, unsigned st, double reps, 
 template <int F>
 OGG_DEV void dq_chord_point(const double* r, const cplx* ep, const DpConst& c, double reps, double& hi, double& hj) {
     constexpr int H = F / 2;
+    const double inv_rj = 1.0 / c.r_joint;
     double ds[F];
 #pragma unroll
     for (int k = 0; k < F; ++k) {
         double ra, rb;
         cplx epa, epb;
         dq_probe_pair<F>(k, r, ep, ra, rb, epa, epb);
-        ds[k] = gnomonic_arc(dp_gnomonic(ra, epa, c), dp_gnomonic(rb, epb, c));
+        ds[k] = homogeneous_arc(dp_homogeneous(ra, epa, c, inv_rj), dp_homogeneous(rb, epb, c, inv_rj));
     }
     hi = central_difference<F>(ds, reps);
     hj = central_difference<F>(ds + H, reps);
@@ -527,7 +572,9 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
             double ah[N], ap[N];                  // h_i and h_i h_j at this column and its M right-hand neighbours
             ah[0] = hi, ap[0] = pr;
 #pragma unroll
-            for (int i = 1; i < N; ++i) ah[i] = wave_next(ah[i - 1]), ap[i] = wave_next(ap[i - 1]);
+            for (int i = 1; i < N; ++i) ap[i] = wave_next(ap[i - 1]);
+#pragma unroll
+            for (int i = 1; i < N; ++i) ah[i] = (jj == 0) ? wave_next(ah[i - 1]) : 0.0;   // only a cell row's bottom edge feeds dxq
             if (jj == 0 && k > 0) {               // top edge of cell row k - 1: its last Lobatto row
 #pragma unroll
                 for (int i = 0; i < N; ++i) ysum = ysum + dq_weight<N>(i) * dq_weight<N>(M) * ap[i];   // OGG:244 / 231
@@ -604,7 +651,7 @@ OGG_DEV void dpole_mesh_body(const DpMeshParams& m, DpMeshLds& s, long bx, long 
     const cplx ep = dp_column((double)i, m.g, c);
     const double seed = m.g.lon0 + (0.0 * 360.0) / (double)Ni;   // lon_grid[0,0] (OGG:463)
     double v_cur = 0.0, ph_cur = 0.0, v_nxt = 0.0, ph_nxt = 0.0;
-    unsigned i0 = 0u, i1 = 1u, n0 = 0u, n1 = 1u;
+    unsigned long long cC = 0ull, cV = 0ull, nC = 0ull, nV = 0ull;
 #pragma unroll 1
     for (int r = -1; r < nr; ++r) {
         if (r + 1 < nr) {
@@ -619,15 +666,19 @@ OGG_DEV void dpole_mesh_body(const DpMeshParams& m, DpMeshLds& s, long bx, long 
                 f0 = (v_nxt - vp > 100) ? 1u : 0u;        // OGG:473-474
                 f1 = (v_nxt - (vp - 360) > 100) ? 1u : 0u;
             }
-            map_scan(f0, f1);
-            n0 = f0, n1 = f1;
-            // the strip's own map: its columns col0 .. col0+61 are lanes 1 .. 62
-            if (lane == DM_OUT) lb_publish(m.words + (jl0 + r + 1) * m.n_strips + strip, f0, f1);
+            // constant maps of the wave (C) and their values (V); the strip's own map covers its columns col0 .. col0+61 = lanes 1 .. 62
+            nC = __ballot(f0 == f1), nV = __ballot(f0 != 0u);
+            if (lane == DM_OUT) {
+                const unsigned long long own = nC & 0x7ffffffffffffffeull;
+                const unsigned v = own ? (unsigned)((nV >> (63 - __builtin_clzll(own))) & 1ull) : 0u;
+                lb_publish(m.words + (jl0 + r + 1) * m.n_strips + strip, own ? v : 0u, own ? v : 1u);
+            }
         }
         if (r >= 0) {
             const long jl = jl0 + r;
-            const unsigned s_in = (strip > 0) ? lb_incoming(m.words + jl * m.n_strips, strip, 1u, (int*)(m.ticket + 1)) : 0u;
-            const unsigned st = map_apply(i0, i1, s_in);
+            const unsigned s_in = (strip > 0) ? lb_incoming1(m.words + jl * m.n_strips, strip, (int*)(m.ticket + 1)) : 0u;
+            const unsigned long long upto = cC & (~0ull >> (63 - lane));          // constant maps at or before this lane
+            const unsigned st = upto ? (unsigned)((cV >> (63 - __builtin_clzll(upto))) & 1ull) : s_in;
             const double lam = st ? v_cur - 360 : v_cur;  // OGG:473
             const double phi = ph_cur;
             if (out) {
@@ -649,7 +700,7 @@ OGG_DEV void dpole_mesh_body(const DpMeshParams& m, DpMeshLds& s, long bx, long 
             }
         }
         v_cur = v_nxt, ph_cur = ph_nxt;
-        i0 = n0, i1 = n1;
+        cC = nC, cV = nV;
     }
 }
 
