@@ -4,6 +4,8 @@
 // returns OGG_EHIP.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "ogg_common.h"
@@ -20,43 +22,130 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-// scratch device buffers of one call, freed on scope exit
+// ---- staging of the host-pointer layer --------------------------------------------------------------------------------------
+// One call at a time (a process-wide mutex: the reference is single-threaded, ctypes releases the GIL).  Device scratch comes from a
+// grow-only arena that is kept between calls (no hipMalloc / hipFree per call); host <-> device transfers go through two pinned
+// buffers on a private non-blocking stream -- the copy engine fills / drains one while the CPU copies the other to / from the
+// caller's (pageable) array -- so nothing runs on the null stream and nothing serialises with the caller's own streams.
+namespace {
+
+constexpr size_t kStageBytes = 8u << 20;
+
+struct Staging {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    void* pinned[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    std::vector<std::pair<char*, size_t>> blocks;   // device arena: blocks of the current call (one block in the steady state)
+    size_t used = 0;                                // bytes taken from blocks.back()
+
+    int init() {
+        if (stream) return OGG_OK;
+        OGG_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            OGG_HIP_CHECK(hipHostMalloc(&pinned[k], kStageBytes, hipHostMallocDefault));
+            OGG_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
+        return OGG_OK;
+    }
+    int take(void** out, size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (blocks.empty() || used + bytes > blocks.back().second) {
+            size_t total = bytes;
+            for (auto& b : blocks) total += b.second;
+            void* p = nullptr;
+            hipError_t e = hipMalloc(&p, total);
+            if (e != hipSuccess) {
+                const int code = (e == hipErrorOutOfMemory) ? OGG_ENOMEM : OGG_EHIP;
+                return set_error(code, "hipMalloc(%zu bytes) failed: %s", total, hipGetErrorString(e));
+            }
+            blocks.emplace_back(static_cast<char*>(p), total);
+            used = 0;
+        }
+        *out = blocks.back().first + used;
+        used += bytes;
+        return OGG_OK;
+    }
+    void release() {   // end of a call: keep the largest block (it holds the sum of all earlier ones), free the rest
+        while (blocks.size() > 1) {
+            (void)hipFree(blocks.front().first);
+            blocks.erase(blocks.begin());
+        }
+        used = 0;
+    }
+};
+
+Staging g_staging;
+
+}  // namespace
+
+// scratch device buffers and transfers of one host-pointer call
 class DevScratch {
    public:
+    DevScratch() : lock_(g_staging.mu) {}
     ~DevScratch() {
-        for (void* p : ptrs_) (void)hipFree(p);
+        if (g_staging.stream) (void)hipStreamSynchronize(g_staging.stream);
+        g_staging.release();
     }
+    void* stream() { return g_staging.stream; }
     int alloc(double** out, long n) {
+        if (int e = g_staging.init()) return e;
         void* p = nullptr;
-        const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            const int code = (e == hipErrorOutOfMemory) ? OGG_ENOMEM : OGG_EHIP;
-            return set_error(code, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        }
-        ptrs_.push_back(p);
+        if (int e = g_staging.take(&p, (size_t)(n > 0 ? n : 1) * sizeof(double))) return e;
         *out = static_cast<double*>(p);
         return OGG_OK;
     }
     int upload(double** out, const double* host, long n) {
         if (int e = alloc(out, n)) return e;
-        if (n > 0) OGG_HIP_CHECK(hipMemcpy(*out, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        const size_t bytes = (size_t)(n > 0 ? n : 0) * sizeof(double);
+        const char* src = reinterpret_cast<const char*>(host);
+        char* dst = reinterpret_cast<char*>(*out);
+        int k = 0;
+        for (size_t off = 0; off < bytes; off += kStageBytes, k ^= 1) {
+            const size_t len = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+            OGG_HIP_CHECK(hipEventSynchronize(g_staging.done[k]));   // the copy that last read this buffer has finished
+            memcpy(g_staging.pinned[k], src + off, len);
+            OGG_HIP_CHECK(hipMemcpyAsync(dst + off, g_staging.pinned[k], len, hipMemcpyHostToDevice, g_staging.stream));
+            OGG_HIP_CHECK(hipEventRecord(g_staging.done[k], g_staging.stream));
+        }
+        return OGG_OK;
+    }
+    // device -> caller's array, after everything enqueued on the stream so far
+    int download(void* host, const void* dev, size_t bytes) {
+        if (!host || bytes == 0) return OGG_OK;
+        char* dst = reinterpret_cast<char*>(host);
+        const char* src = reinterpret_cast<const char*>(dev);
+        size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};
+        int k = 0;
+        for (size_t off = 0; off < bytes; off += kStageBytes, k ^= 1) {
+            const size_t len = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+            if (pending_len[k]) {   // drain the chunk that sits in this buffer before the engine overwrites it
+                OGG_HIP_CHECK(hipEventSynchronize(g_staging.done[k]));
+                memcpy(dst + pending_off[k], g_staging.pinned[k], pending_len[k]);
+            }
+            OGG_HIP_CHECK(hipMemcpyAsync(g_staging.pinned[k], src + off, len, hipMemcpyDeviceToHost, g_staging.stream));
+            OGG_HIP_CHECK(hipEventRecord(g_staging.done[k], g_staging.stream));
+            pending_off[k] = off, pending_len[k] = len;
+        }
+        for (int j = 0; j < 2; ++j, k ^= 1) {   // oldest first
+            if (pending_len[k]) {
+                OGG_HIP_CHECK(hipEventSynchronize(g_staging.done[k]));
+                memcpy(dst + pending_off[k], g_staging.pinned[k], pending_len[k]);
+                pending_len[k] = 0;
+            }
+        }
         return OGG_OK;
     }
 
    private:
-    std::vector<void*> ptrs_;
+    std::lock_guard<std::mutex> lock_;
 };
-
-static int download(double* host, const double* dev, long n) {
-    if (n > 0 && host) OGG_HIP_CHECK(hipMemcpy(host, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    return OGG_OK;
-}
 
 }  // namespace ogg
 
 using ogg::DevScratch;
-using ogg::download;
+
+#define OGG_DOWNLOAD(host, dev, n) s.download((host), (dev), (size_t)((n) > 0 ? (n) : 0) * sizeof(double))
 
 #define OGG_TRY(expr)          \
     do {                       \
@@ -129,9 +218,8 @@ int ogg_y_mercator_rounded(long Ni, long n, const double* phi_rad, long long* ys
     double *d_phi, *d_y;
     OGG_TRY(s.upload(&d_phi, phi_rad, n));
     OGG_TRY(s.alloc(&d_y, n));
-    OGG_TRY(ogg_y_mercator_rounded_dev(Ni, n, d_phi, reinterpret_cast<long long*>(d_y), nullptr));
-    if (n > 0) OGG_HIP_CHECK(hipMemcpy(ystar, d_y, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
-    return OGG_OK;
+    OGG_TRY(ogg_y_mercator_rounded_dev(Ni, n, d_phi, reinterpret_cast<long long*>(d_y), s.stream()));
+    return s.download(ystar, d_y, (size_t)n * sizeof(long long));
 }
 
 int ogg_phi_mercator(long Ni, long n, const double* y, double* phi_deg) {
@@ -140,8 +228,8 @@ int ogg_phi_mercator(long Ni, long n, const double* y, double* phi_deg) {
     double *d_y, *d_phi;
     OGG_TRY(s.upload(&d_y, y, n));
     OGG_TRY(s.alloc(&d_phi, n));
-    OGG_TRY(ogg_phi_mercator_dev(Ni, n, d_y, d_phi, nullptr));
-    return download(phi_deg, d_phi, n);
+    OGG_TRY(ogg_phi_mercator_dev(Ni, n, d_y, d_phi, s.stream()));
+    return OGG_DOWNLOAD(phi_deg, d_phi, n);
 }
 
 int ogg_tile_latlon(long nrows, long ni1, const double* lat1d, const double* lon1d, double* x, double* y) {
@@ -152,9 +240,9 @@ int ogg_tile_latlon(long nrows, long ni1, const double* lat1d, const double* lon
     OGG_TRY(s.upload(&d_lon, lon1d, ni1));
     OGG_TRY(s.alloc(&d_x, nrows * ni1));
     OGG_TRY(s.alloc(&d_y, nrows * ni1));
-    OGG_TRY(ogg_tile_latlon_dev(nrows, ni1, d_lat, d_lon, d_x, d_y, nullptr));
-    OGG_TRY(download(x, d_x, nrows * ni1));
-    return download(y, d_y, nrows * ni1);
+    OGG_TRY(ogg_tile_latlon_dev(nrows, ni1, d_lat, d_lon, d_x, d_y, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(x, d_x, nrows * ni1));
+    return OGG_DOWNLOAD(y, d_y, nrows * ni1);
 }
 
 int ogg_generate_latlon_grid(long lni, long lnj, double llon0, double llen_lon, double llat0, double llen_lat,
@@ -168,11 +256,11 @@ int ogg_generate_latlon_grid(long lni, long lnj, double llon0, double llen_lon, 
     OGG_TRY(s.alloc(&d_lon, ni1));
     OGG_TRY(s.alloc(&d_x, nrows * ni1));
     OGG_TRY(s.alloc(&d_y, nrows * ni1));
-    OGG_TRY(ogg_linear_axis_dev(ni1, llon0, llen_lon, (double)lni, d_lon, nullptr));      // OGG:834
-    OGG_TRY(ogg_linear_axis_dev(lnj + 1, llat0, llen_lat, (double)lnj, d_lat, nullptr));  // OGG:835
-    OGG_TRY(ogg_tile_latlon_dev(nrows, ni1, d_lat + skip, d_lon, d_x, d_y, nullptr));
-    OGG_TRY(download(x, d_x, nrows * ni1));
-    return download(y, d_y, nrows * ni1);
+    OGG_TRY(ogg_linear_axis_dev(ni1, llon0, llen_lon, (double)lni, d_lon, s.stream()));      // OGG:834
+    OGG_TRY(ogg_linear_axis_dev(lnj + 1, llat0, llen_lat, (double)lnj, d_lat, s.stream()));  // OGG:835
+    OGG_TRY(ogg_tile_latlon_dev(nrows, ni1, d_lat + skip, d_lon, d_x, d_y, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(x, d_x, nrows * ni1));
+    return OGG_DOWNLOAD(y, d_y, nrows * ni1);
 }
 
 // ---- MIDAS + angle -----------------------------------------------------------------------------------------
@@ -187,10 +275,10 @@ int ogg_grid_metrics_midas(long nj1, long ni1, const double* x, const double* y,
     OGG_TRY(s.alloc(&d_dx, nj1 * (ni1 - 1)));
     OGG_TRY(s.alloc(&d_dy, (nj1 - 1) * ni1));
     OGG_TRY(s.alloc(&d_ar, (nj1 - 1) * (ni1 - 1)));
-    OGG_TRY(ogg_grid_metrics_midas_dev(nj1, ni1, d_x, d_y, nj1, nj1 - 1, Re, latlon_areafix, d_dx, d_dy, d_ar, nullptr, nullptr));
-    OGG_TRY(download(dx, d_dx, nj1 * (ni1 - 1)));
-    OGG_TRY(download(dy, d_dy, (nj1 - 1) * ni1));
-    return download(area, d_ar, (nj1 - 1) * (ni1 - 1));
+    OGG_TRY(ogg_grid_metrics_midas_dev(nj1, ni1, d_x, d_y, nj1, nj1 - 1, Re, latlon_areafix, d_dx, d_dy, d_ar, nullptr, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(dx, d_dx, nj1 * (ni1 - 1)));
+    OGG_TRY(OGG_DOWNLOAD(dy, d_dy, (nj1 - 1) * ni1));
+    return OGG_DOWNLOAD(area, d_ar, (nj1 - 1) * (ni1 - 1));
 }
 
 int ogg_angle_x(long nj1, long ni1, const double* x, const double* y, double* angle_dx) {
@@ -201,8 +289,8 @@ int ogg_angle_x(long nj1, long ni1, const double* x, const double* y, double* an
     OGG_TRY(s.upload(&d_x, x, nj1 * ni1));
     OGG_TRY(s.upload(&d_y, y, nj1 * ni1));
     OGG_TRY(s.alloc(&d_a, nj1 * ni1));
-    OGG_TRY(ogg_grid_metrics_midas_dev(nj1, ni1, d_x, d_y, nj1, 0, 6371.0e3, 1, nullptr, nullptr, nullptr, d_a, nullptr));
-    return download(angle_dx, d_a, nj1 * ni1);
+    OGG_TRY(ogg_grid_metrics_midas_dev(nj1, ni1, d_x, d_y, nj1, 0, 6371.0e3, 1, nullptr, nullptr, nullptr, d_a, s.stream()));
+    return OGG_DOWNLOAD(angle_dx, d_a, nj1 * ni1);
 }
 
 // ---- bipolar cap -------------------------------------------------------------------------------------------
@@ -218,13 +306,13 @@ int ogg_bipolar_projection(long n, const double* lamg, const double* phig, doubl
     OGG_TRY(s.alloc(&d_ps, n));
     OGG_TRY(s.alloc(&d_hi, n));
     OGG_TRY(s.alloc(&d_hj, n));
-    OGG_TRY(ogg_bipolar_projection_dev(n, d_l, d_p, lon_bp, rp, metrics_only, d_ls, d_ps, d_hi, d_hj, nullptr));
+    OGG_TRY(ogg_bipolar_projection_dev(n, d_l, d_p, lon_bp, rp, metrics_only, d_ls, d_ps, d_hi, d_hj, s.stream()));
     if (!metrics_only) {
-        OGG_TRY(download(lams, d_ls, n));
-        OGG_TRY(download(phis, d_ps, n));
+        OGG_TRY(OGG_DOWNLOAD(lams, d_ls, n));
+        OGG_TRY(OGG_DOWNLOAD(phis, d_ps, n));
     }
-    OGG_TRY(download(h_i_inv, d_hi, n));
-    return download(h_j_inv, d_hj, n);
+    OGG_TRY(OGG_DOWNLOAD(h_i_inv, d_hi, n));
+    return OGG_DOWNLOAD(h_j_inv, d_hj, n);
 }
 
 int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis, double* h_i_inv,
@@ -237,11 +325,11 @@ int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double
     OGG_TRY(s.alloc(&d_ps, n));
     if (h_i_inv) OGG_TRY(s.alloc(&d_hi, (Nj + 1) * Ni));
     if (h_j_inv) OGG_TRY(s.alloc(&d_hj, Nj * (Ni + 1)));
-    OGG_TRY(ogg_bipolar_cap_mesh_dev(Ni, Nj, lat0_bp, lon_bp, 0, Nj + 1, d_ls, d_ps, d_hi, d_hj, nullptr));
-    OGG_TRY(download(lams, d_ls, n));
-    OGG_TRY(download(phis, d_ps, n));
-    if (h_i_inv) OGG_TRY(download(h_i_inv, d_hi, (Nj + 1) * Ni));
-    if (h_j_inv) OGG_TRY(download(h_j_inv, d_hj, Nj * (Ni + 1)));
+    OGG_TRY(ogg_bipolar_cap_mesh_dev(Ni, Nj, lat0_bp, lon_bp, 0, Nj + 1, d_ls, d_ps, d_hi, d_hj, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(lams, d_ls, n));
+    OGG_TRY(OGG_DOWNLOAD(phis, d_ps, n));
+    if (h_i_inv) OGG_TRY(OGG_DOWNLOAD(h_i_inv, d_hi, (Nj + 1) * Ni));
+    if (h_j_inv) OGG_TRY(OGG_DOWNLOAD(h_j_inv, d_hj, Nj * (Ni + 1)));
     return OGG_OK;
 }
 
@@ -254,10 +342,10 @@ int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, do
     OGG_TRY(s.alloc(&d_dx, (ny + 1) * nx));
     OGG_TRY(s.alloc(&d_dy, ny * (nx + 1)));
     OGG_TRY(s.alloc(&d_da, ny * nx));
-    OGG_TRY(ogg_bipolar_cap_metrics_quad_dev(order, nx, ny, lat0_bp, lon_bp, rp, Re, 0, ny + 1, ny, d_dx, d_dy, d_da, nullptr));
-    OGG_TRY(download(dxq, d_dx, (ny + 1) * nx));
-    OGG_TRY(download(dyq, d_dy, ny * (nx + 1)));
-    return download(daq, d_da, ny * nx);
+    OGG_TRY(ogg_bipolar_cap_metrics_quad_dev(order, nx, ny, lat0_bp, lon_bp, rp, Re, 0, ny + 1, ny, d_dx, d_dy, d_da, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(dxq, d_dx, (ny + 1) * nx));
+    OGG_TRY(OGG_DOWNLOAD(dyq, d_dy, ny * (nx + 1)));
+    return OGG_DOWNLOAD(daq, d_da, ny * nx);
 }
 
 // ---- displaced pole cap ------------------------------------------------------------------------------------
@@ -270,9 +358,9 @@ int ogg_displaced_pole_mesh(long n_i, const double* i, long n_j, const double* j
     OGG_TRY(s.upload(&d_j, j, n_j));
     OGG_TRY(s.alloc(&d_l, n_i * n_j));
     OGG_TRY(s.alloc(&d_p, n_i * n_j));
-    OGG_TRY(ogg_displaced_pole_mesh_dev(n_i, d_i, n_j, d_j, ni, nj, lon0, lat0, lam_pole, r_pole, d_l, d_p, nullptr));
-    OGG_TRY(download(lams, d_l, n_i * n_j));
-    return download(phis, d_p, n_i * n_j);
+    OGG_TRY(ogg_displaced_pole_mesh_dev(n_i, d_i, n_j, d_j, ni, nj, lon0, lat0, lam_pole, r_pole, d_l, d_p, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(lams, d_l, n_i * n_j));
+    return OGG_DOWNLOAD(phis, d_p, n_i * n_j);
 }
 
 int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const double* j, long nx, long ny, double lon0,
@@ -284,9 +372,9 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
     OGG_TRY(s.upload(&d_j, j, n_j));
     if (h_i) OGG_TRY(s.alloc(&d_hi, n_i * n_j));
     if (h_j) OGG_TRY(s.alloc(&d_hj, n_i * n_j));
-    OGG_TRY(ogg_displaced_pole_numerical_h_dev(n_i, d_i, n_j, d_j, nx, ny, lon0, lat0, lon_dp, r_dp, eps, fd_order, d_hi, d_hj, nullptr));
-    if (h_i) OGG_TRY(download(h_i, d_hi, n_i * n_j));
-    if (h_j) OGG_TRY(download(h_j, d_hj, n_i * n_j));
+    OGG_TRY(ogg_displaced_pole_numerical_h_dev(n_i, d_i, n_j, d_j, nx, ny, lon0, lat0, lon_dp, r_dp, eps, fd_order, d_hi, d_hj, s.stream()));
+    if (h_i) OGG_TRY(OGG_DOWNLOAD(h_i, d_hi, n_i * n_j));
+    if (h_j) OGG_TRY(OGG_DOWNLOAD(h_j, d_hj, n_i * n_j));
     return OGG_OK;
 }
 
@@ -303,12 +391,12 @@ int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long 
     OGG_TRY(s.alloc(&d_da, ny * nx));
     OGG_TRY(s.alloc(&d_ws, (ws_bytes + 7) / 8));
     OGG_TRY(ogg_displaced_pole_metrics_quad_form_ws_dev(arc_form, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, 0, ny + 1, ny, d_dx, d_dy,
-                                                        d_da, d_ws, ws_bytes, nullptr));
-    OGG_TRY(download(dxq, d_dx, (ny + 1) * nx));
-    OGG_TRY(download(dyq, d_dy, ny * (nx + 1)));
-    OGG_TRY(download(daq, d_da, ny * nx));
+                                                        d_da, d_ws, ws_bytes, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(dxq, d_dx, (ny + 1) * nx));
+    OGG_TRY(OGG_DOWNLOAD(dyq, d_dy, ny * (nx + 1)));
+    OGG_TRY(OGG_DOWNLOAD(daq, d_da, ny * nx));
     int flag = 0;
-    OGG_TRY(ogg_workspace_error_flag_dev(d_ws, &flag, nullptr));
+    OGG_TRY(ogg_workspace_error_flag_dev(d_ws, &flag, s.stream()));
     OGG_REQUIRE(flag == 0, OGG_EHIP, "ogg_displaced_pole_metrics_quad: a look-back wait timed out (flag %d)", flag);
     return OGG_OK;
 }
@@ -325,8 +413,8 @@ int ogg_y_mercator(long Ni, long n, const double* phi_rad, double* y) {
     double *d_in, *d_out;
     OGG_TRY(s.upload(&d_in, phi_rad, n));
     OGG_TRY(s.alloc(&d_out, n));
-    OGG_TRY(ogg_y_mercator_dev(Ni, n, d_in, d_out, nullptr));
-    return download(y, d_out, n);
+    OGG_TRY(ogg_y_mercator_dev(Ni, n, d_in, d_out, s.stream()));
+    return OGG_DOWNLOAD(y, d_out, n);
 }
 
 int ogg_affine_index(long n, const double* idx, double a0, double len, double denom, double* out) {
@@ -335,8 +423,8 @@ int ogg_affine_index(long n, const double* idx, double a0, double len, double de
     double *d_in, *d_out;
     OGG_TRY(s.upload(&d_in, idx, n));
     OGG_TRY(s.alloc(&d_out, n));
-    OGG_TRY(ogg_affine_index_dev(n, d_in, a0, len, denom, d_out, nullptr));
-    return download(out, d_out, n);
+    OGG_TRY(ogg_affine_index_dev(n, d_in, a0, len, denom, d_out, s.stream()));
+    return OGG_DOWNLOAD(out, d_out, n);
 }
 
 int ogg_mdist(long n, const double* x1, const double* x2, double* out) {
@@ -346,8 +434,8 @@ int ogg_mdist(long n, const double* x1, const double* x2, double* out) {
     OGG_TRY(s.upload(&d_a, x1, n));
     OGG_TRY(s.upload(&d_b, x2, n));
     OGG_TRY(s.alloc(&d_out, n));
-    OGG_TRY(ogg_mdist_dev(n, d_a, d_b, d_out, nullptr));
-    return download(out, d_out, n);
+    OGG_TRY(ogg_mdist_dev(n, d_a, d_b, d_out, s.stream()));
+    return OGG_DOWNLOAD(out, d_out, n);
 }
 
 int ogg_haversine(long n, const double* lam0, const double* phi0, const double* lam1, const double* phi1, double* out) {
@@ -359,8 +447,8 @@ int ogg_haversine(long n, const double* lam0, const double* phi0, const double* 
     OGG_TRY(s.upload(&d2, lam1, n));
     OGG_TRY(s.upload(&d3, phi1, n));
     OGG_TRY(s.alloc(&d_out, n));
-    OGG_TRY(ogg_haversine_dev(n, d0, d1, d2, d3, d_out, nullptr));
-    return download(out, d_out, n);
+    OGG_TRY(ogg_haversine_dev(n, d0, d1, d2, d3, d_out, s.stream()));
+    return OGG_DOWNLOAD(out, d_out, n);
 }
 
 int ogg_bipolar_cap_ij_array(long n_i, const double* i, long n_j, const double* j, long Ni, long Nj, double lat0_bp,
@@ -372,9 +460,9 @@ int ogg_bipolar_cap_ij_array(long n_i, const double* i, long n_j, const double* 
     OGG_TRY(s.upload(&d_j, j, n_j));
     OGG_TRY(s.alloc(&d_hi, n_i * n_j));
     OGG_TRY(s.alloc(&d_hj, n_i * n_j));
-    OGG_TRY(ogg_bipolar_cap_ij_array_dev(n_i, d_i, n_j, d_j, Ni, Nj, lat0_bp, lon_bp, rp, d_hi, d_hj, nullptr));
-    OGG_TRY(download(h_i_inv, d_hi, n_i * n_j));
-    return download(h_j_inv, d_hj, n_i * n_j);
+    OGG_TRY(ogg_bipolar_cap_ij_array_dev(n_i, d_i, n_j, d_j, Ni, Nj, lat0_bp, lon_bp, rp, d_hi, d_hj, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(h_i_inv, d_hi, n_i * n_j));
+    return OGG_DOWNLOAD(h_j_inv, d_hj, n_i * n_j);
 }
 
 int ogg_displaced_pole_projection(long nj, long ni, const double* lon_grid, const double* lat_grid, double z0_re, double z0_im,
@@ -386,9 +474,9 @@ int ogg_displaced_pole_projection(long nj, long ni, const double* lon_grid, cons
     OGG_TRY(s.upload(&d_lat, lat_grid, nj * ni));
     OGG_TRY(s.alloc(&d_l, nj * ni));
     OGG_TRY(s.alloc(&d_p, nj * ni));
-    OGG_TRY(ogg_displaced_pole_projection_dev(nj, ni, d_lon, d_lat, z0_re, z0_im, r_joint, x_0, d_l, d_p, nullptr));
-    OGG_TRY(download(lam, d_l, nj * ni));
-    return download(phi, d_p, nj * ni);
+    OGG_TRY(ogg_displaced_pole_projection_dev(nj, ni, d_lon, d_lat, z0_re, z0_im, r_joint, x_0, d_l, d_p, s.stream()));
+    OGG_TRY(OGG_DOWNLOAD(lam, d_l, nj * ni));
+    return OGG_DOWNLOAD(phi, d_p, nj * ni);
 }
 
 int ogg_monotonic_bounding(long nj, long ni, double* x, double x_0) {
@@ -396,8 +484,8 @@ int ogg_monotonic_bounding(long nj, long ni, double* x, double x_0) {
     DevScratch s;
     double* d_x;
     OGG_TRY(s.upload(&d_x, x, nj * ni));
-    OGG_TRY(ogg_monotonic_bounding_dev(nj, ni, d_x, x_0, nullptr));
-    return download(x, d_x, nj * ni);
+    OGG_TRY(ogg_monotonic_bounding_dev(nj, ni, d_x, x_0, s.stream()));
+    return OGG_DOWNLOAD(x, d_x, nj * ni);
 }
 
 }  // extern "C"

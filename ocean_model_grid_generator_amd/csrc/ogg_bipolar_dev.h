@@ -715,8 +715,9 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, 
     const size_t need = quad_workspace_bytes<N>(p.nx, p.ny, n_cell_rows);
     void* ws = ext_ws;
     long ws_bytes = ext_ws_bytes;
+    ogg::AsyncScratch own(s);   // returned to the stream-ordered allocator on every exit path
     if (!ext_ws) {
-        OGG_HIP_CHECK(hipMallocAsync(&ws, need, s));
+        if (int e = own.alloc(&ws, need)) return e;
         ws_bytes = (long)need;
     }
     QuadPlan q;
@@ -731,9 +732,7 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, 
         bipolar_quad_kernel<N, QM_GUARD><<<dim3(q.gx, q.guard.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.guard);
         OGG_LAUNCH_CHECK();
     }
-    if (int e = launch_quad_tail<N>(q, s)) return e;
-    if (!ext_ws) OGG_HIP_CHECK(hipFreeAsync(ws, s));
-    return OGG_OK;
+    return launch_quad_tail<N>(q, s);
 }
 
 }  // namespace

@@ -72,11 +72,13 @@ extern "C" int ogg_metrics_sums_dev(long n_dx_rows, long n_cell_rows, long ni, c
     OGG_REQUIRE(col_a >= 0 && col_a <= ni && col_b <= ni, OGG_ESHAPE, "ogg_metrics_sums: column %ld / %ld outside 0..%ld", col_a, col_b, ni);
     hipStream_t st = ogg::as_stream(stream);
     SumParams p{n_dx_rows, n_cell_rows, ni, dx, dy, area, col_a, col_b, want_first_row, want_last_row, nullptr, out5};
-    OGG_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&p.partial), (RED_AREA_BLOCKS + 4) * sizeof(double), st));
+    ogg::AsyncScratch scratch(st);   // returned to the stream-ordered allocator on every exit path
+    void* partial = nullptr;
+    if (int e = scratch.alloc(&partial, (RED_AREA_BLOCKS + 4) * sizeof(double))) return e;
+    p.partial = static_cast<double*>(partial);
     metrics_partial_kernel<<<RED_AREA_BLOCKS + 4, RED_TX, 0, st>>>(p);
     OGG_LAUNCH_CHECK();
     metrics_final_kernel<<<1, RED_TX, 0, st>>>(p);
     OGG_LAUNCH_CHECK();
-    OGG_HIP_CHECK(hipFreeAsync(p.partial, st));
     return OGG_OK;
 }
