@@ -360,27 +360,50 @@ def main():
                           "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         pmc = json.load(open(tfile)).get(args.workload, {}) if os.path.exists(tfile) else {}
+        vfile = os.path.join(ROOT, "profiles", "valu_counters.json")
+        vkey = args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else "")
+        valu = json.load(open(vfile)).get(vkey, {}) if os.path.exists(vfile) else {}
+        roof_valu = None
         if launches:  # the launches of the fused pass, timed inside the timed region
             n_sampled = launches.pop("sampled_passes")
+            if launches.get("pass_dpquad", {}).get("alg_bytes", 0) == 0:
+                launches.pop("pass_dpquad", None)   # no fourth launch in this pass (two events back to back)
             for k, v in launches.items():
                 gbs = v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
                 v.update({"ms": round(v["ms"], 5), "alg_bytes": int(v["alg_bytes"]), "alg_GBps": round(gbs, 1),
                           "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
             dom = max(launches, key=lambda k: launches[k]["ms"])
-            roof = {"kernel": {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5>", "pass_tail": "bipolar_quad_tail_kernel<5>",
-                               "pass_dpquad": "pass_d_kernel<4>"}[dom],
-                    "bound": "hbm", "achieved": launches[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            kname = {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5>", "pass_tail": "bipolar_quad_tail_kernel<5>",
+                     "pass_dpquad": "pass_d_kernel<4>"}[dom]
+            vc = valu.get(kname)
+            roof = {"kernel": kname, "bound": "hbm", "achieved": launches[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": launches[dom]["hbm_frac"], "traffic": pmc.get(dom),
-                    "note": "longest of the three launches of the fused pass; HIP events recorded by the library on the launch stream in "
-                            "%d passes of the timed region.  It carries lat-lon row strips (HBM-write bound) AND bipolar quadrature "
+                    "traffic_source": "profiles/hbm_traffic.json: FETCH_SIZE / WRITE_SIZE passes of a builder-side rocprofv3 run of this command "
+                                      "(read side x2), committed -- not counters of this process",
+                    "limited_by": "fp64 VALU issue, not HBM (see roofline_valu)" if (vc and vc["valu_busy_frac"] > 0.6) else None,
+                    "note": "longest of the launches of the fused pass; HIP events recorded by the library on the launch stream in "
+                            "%d passes of the timed region.  It carries lat-lon row strips (HBM-write bound) AND cap mesh / quadrature "
                             "workgroups (fp64-VALU bound, DESIGN.md 4): its duration is set by the VALU work, its bytes mostly by the "
-                            "lat-lon strips.  `kernels` lists the stand-alone kernels, one after the other." % n_sampled}
+                            "lat-lon strips, so `frac` is what the WORKLOAD allows, not a statement about the write path.  `kernels` lists the "
+                            "stand-alone kernels, one after the other." % n_sampled}
+            if vc:
+                # issue-time floor of the launch: every wave64 VALU instruction occupies its SIMD for >= 4 cycles (quarter-rate fp64
+                # rcp/rsq/sqrt: 16), 1024 SIMDs, at the clock the counter run held
+                clock_ghz = vc["gui_cycles_per_xcd"] / (launches[dom]["ms"] * 1e-3) / 1e9
+                roof_valu = {"kernel": kname, "bound": "fp64 VALU issue", "valu_busy_frac": round(vc["valu_busy_frac"], 4),
+                             "wave64_valu_instr_per_launch": vc["wave64_valu_instr"], "fp64_transcendental_instr": vc["fp64_transcendental_instr"],
+                             "issue_floor_ms": round(vc["valu_busy_frac"] * vc["gui_cycles_per_xcd"] / (clock_ghz * 1e9) * 1e3, 5) if clock_ghz > 0 else None,
+                             "launch_ms": launches[dom]["ms"],
+                             "source": "profiles/valu_counters.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE of a builder-side "
+                                       "rocprofv3 --pmc run of this command, committed -- not counters of this process; launch_ms is this "
+                                       "run's own event time"}
         else:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             per_step = pmc.get(dom)  # PMC bytes per step of that kernel
             traffic = int(per_step / kernels[dom]["launches_per_step"]) if per_step else None
             roof = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[dom]["hbm_frac"], "traffic": traffic,
+                    "traffic_source": "profiles/hbm_traffic.json (builder-side rocprofv3 run, committed)",
                     "note": "per-kernel durations from the sequential events pass; latlon_fused (78 % of the cells) is the HBM-bound "
                             "kernel, the cap kernels are fp64-VALU bound (DESIGN.md 4)"}
         out = {
@@ -394,7 +417,7 @@ def main():
             "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned,
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
-            "roofline": roof, "pass_launches": launches,
+            "roofline": roof, "roofline_valu": roof_valu, "pass_launches": launches,
             "parity": _dp_parity(args.dp_arc) if has_dp else None,
             "self_check_metrics_error_percent": self_check, "field_checksums": checksums,
             "d2h_pinned_after_pass": d2h,

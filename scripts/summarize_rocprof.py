@@ -18,7 +18,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHORT = [("pass_a_kernel", "pass_a"), ("pass_b_kernel", "pass_b"), ("bipolar_quad_tail_kernel", "pass_tail"),
+SHORT = [("pass_a_kernel", "pass_a"), ("pass_b_kernel", "pass_b"), ("bipolar_quad_tail_kernel", "pass_tail"), ("pass_d_kernel", "pass_dpquad"),
+         ("dpole_mesh_kernel", "dpole_mesh"), ("dpole_mesh_reset_kernel", "dpole_mesh"), ("dpole_quad_kernel", "dpole_quad"),
+         ("dpole_quad_tables_kernel", "dpole_quad"),
          ("bipolar_quad_kernel", "bipolar_quad"), ("bipolar_tables_kernel", "bipolar_quad"), ("midas_angle_kernel<true", "midas_angle"),
          ("midas_angle_kernel<false", "angle_x"), ("bipolar_mesh_kernel", "bipolar_mesh"), ("tile_latlon_kernel", "tile_latlon"),
          ("dpole_eval_kernel", "dpole_mesh"), ("dpole_unwrap_kernel", "dpole_mesh"), ("dpole_chord", "dpole_quad"), ("dpole_h_kernel", "dpole_quad"), ("dpole_quad_reduce_kernel", "dpole_quad"),
