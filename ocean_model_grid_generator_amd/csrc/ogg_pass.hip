@@ -19,6 +19,8 @@
 // while the compute workgroups stream through the remaining slots).  Every workgroup runs the same body function as the
 // stand-alone kernels of ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level
 // entry points.
+#include <cstring>
+
 #include "ogg_bipolar_dev.h"
 #include "ogg_dpole_dev.h"
 #include "ogg_latlon_fused_dev.h"
@@ -99,7 +101,11 @@ struct PassBParams {
     DpQuadParams dq;        // ... and its quadrature in the chord form (the literal form is launch D)
     long n_dquad;
     int dq_order;
+    int order[5];           // dispatch order of the roles behind the lat-lon strips (ROLE_*)
 };
+
+// roles of launch B's workgroups; PassBParams::order lists them in dispatch order
+enum { ROLE_BP_MESH = 0, ROLE_DP_MESH, ROLE_BP_GUARD, ROLE_BP_FAST, ROLE_DP_QUAD, N_ROLES };
 
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
@@ -111,28 +117,28 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
         return;
     }
     b -= a.share.n_wg;
-    if (b < a.n_mesh) {
-        bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
-        return;
+    int role = -1;
+#pragma unroll
+    for (int k = 0; k < N_ROLES; ++k) {
+        const int r = a.order[k];
+        const long n = (r == ROLE_BP_MESH) ? a.n_mesh : (r == ROLE_DP_MESH) ? a.n_dmesh : (r == ROLE_BP_GUARD) ? a.n_guard : (r == ROLE_BP_FAST) ? a.n_fast : a.n_dquad;
+        if (role < 0) {
+            if (b < n)
+                role = r;
+            else
+                b -= n;
+        }
     }
-    b -= a.n_mesh;
-    if (b < a.n_dmesh) {   // work item from the ticket, not from the workgroup index: see ogg_dpole_dev.h
+    if (role == ROLE_BP_MESH) {
+        bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
+    } else if (role == ROLE_DP_MESH) {   // work item from the ticket, not from the workgroup index: see ogg_dpole_dev.h
         const long t = take_ticket(a.dm.ticket, &s_slot);
         dpole_mesh_body(a.dm, lds.dmesh, t % a.dm.gx, t / a.dm.gx);
-        return;
-    }
-    b -= a.n_dmesh;
-    if (b < a.n_guard) {
+    } else if (role == ROLE_BP_GUARD) {
         bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
-        return;
-    }
-    b -= a.n_guard;
-    if (b < a.n_fast) {
+    } else if (role == ROLE_BP_FAST) {
         bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
-        return;
-    }
-    b -= a.n_fast;
-    if (b < a.n_dquad) {
+    } else if (role == ROLE_DP_QUAD) {
         const long strip = (b % a.dq.gx) * DQ_WAVES + (threadIdx.x >> 6), chunk = b / a.dq.gx;
         if (a.dq_order == 2)
             dpole_quad_body<2, DP_ARC_CHORD>(a.dq, strip, chunk);
@@ -284,6 +290,10 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     }
     if (int e = mark(1)) return e;
     if (launch_b) {
+        // dispatch order of the compute roles: the meshes (short, latency-bound workgroups) first, then the quadrature strips (long,
+        // issue-bound); OGG_PASS_ORDER = permutation of "01234" (ROLE_* ids) for experiments
+        const char* ord = getenv("OGG_PASS_ORDER");
+        for (int k = 0; k < N_ROLES; ++k) B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : k;
         B.share = make_share(ll, s1, n_strips_ll, ni1, false);
         const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
