@@ -8,8 +8,8 @@
 // once the grid is split over 8 GPUs -- each launch carries workgroups of BOTH kinds, told apart by their workgroup index:
 //
 //   launch A:  row/column tables of the quadratures (both caps), reset of the displaced-pole look-back words (a few microseconds)
-//   launch B:  lat-lon row strips  |  bipolar mesh + angle  |  displaced-pole mesh + angle  |  bipolar quadrature strips with the
-//              guard  |  ... without  |  displaced-pole quadrature strips (chord form)
+//   launch B:  lat-lon row strips  |  bipolar quadrature strips without the guard  |  ... with  |  displaced-pole quadrature strips
+//              (chord form)  |  bipolar mesh + angle  |  displaced-pole mesh + angle
 //   launch C:  literal fix-up of the bipolar cells the guard handed over  |  j = ny row of the bipolar quadrature (literal)
 //   launch D:  displaced-pole quadrature strips, literal form (only when asked for)
 // (without metrics and without a displaced-pole cap there is no quadrature: launch A then carries the lat-lon strips and the
@@ -290,10 +290,13 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     }
     if (int e = mark(1)) return e;
     if (launch_b) {
-        // dispatch order of the compute roles: the meshes (short, latency-bound workgroups) first, then the quadrature strips (long,
-        // issue-bound); OGG_PASS_ORDER = permutation of "01234" (ROLE_* ids) for experiments
+        // dispatch order of the compute roles: the quadrature strips first (long, issue-bound waves), the meshes last -- their short
+        // workgroups fill the slots the draining strips leave (2 % faster than meshes first at 1/8 degree, with or without a
+        // displaced-pole cap; scripts/order_sweep.py).  OGG_PASS_ORDER = permutation of "01234" (ROLE_* ids) for experiments
+        static const int dflt[N_ROLES] = {ROLE_BP_FAST, ROLE_BP_GUARD, ROLE_DP_QUAD, ROLE_BP_MESH, ROLE_DP_MESH};
         const char* ord = getenv("OGG_PASS_ORDER");
-        for (int k = 0; k < N_ROLES; ++k) B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : k;
+        for (int k = 0; k < N_ROLES; ++k)
+            B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : dflt[k];
         B.share = make_share(ll, s1, n_strips_ll, ni1, false);
         const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
