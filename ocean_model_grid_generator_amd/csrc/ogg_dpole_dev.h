@@ -237,8 +237,8 @@ struct DpQuadParams {
     long rows_per_chunk;         // cell rows one wave walks (its first lattice row is the last one of the chunk below, recomputed)
     long n_chunks, n_strips, gx; // gx = strip workgroups per chunk
     QuadNodes q;
-    double* row_tab;             // [NV][n_rows]: gnomonic radius of the row variants (base, +eps, -eps, +2eps, -2eps, ...)
-    double* col_tab;             // [NV][2][n_cols]: e' of the column variants
+    const double* row_tab;       // [NV][n_rows]: gnomonic radius of the row variants (base, +eps, -eps, +2eps, -2eps, ...)
+    const double* col_tab;       // [NV][2][n_cols]: e' of the column variants
     unsigned long long* words;   // [n_chunks][M rows_per_chunk + 1][n_strips]: published strip maps (literal form only)
     unsigned* ticket;            // work counter; ticket[1] is the error flag
     double *dxq, *dyq, *daq;
@@ -250,6 +250,8 @@ OGG_DEV void dpole_quad_tables_body(const DpQuadParams& p, long bx, long n_block
     constexpr int M = N - 1, NV = N + 1;
     const long k = bx * blockDim.x + threadIdx.x;
     const DpConst c = dp_const(p.g);
+    double* row_tab = const_cast<double*>(p.row_tab);
+    double* col_tab = const_cast<double*>(p.col_tab);
     if (k == 0) p.ticket[0] = 0u, p.ticket[1] = 0u;
     if (k < p.n_rows * NV) {
         const long row = k / NV;
@@ -259,7 +261,7 @@ OGG_DEV void dpole_quad_tables_body(const DpQuadParams& p, long bx, long n_block
             const double off = (double)((var + 1) / 2) * p.eps;   // OGG:538-543: j + eps, j + 2.0*eps, ...
             jv = (var & 1) ? jv + off : jv - off;
         }
-        p.row_tab[var * p.n_rows + row] = dp_row_radius(jv, p.g, c);
+        row_tab[var * p.n_rows + row] = dp_row_radius(jv, p.g, c);
     } else if (k < p.n_rows * NV + p.n_cols * NV) {
         const long kk = k - p.n_rows * NV;
         const long col = kk / NV;
@@ -270,8 +272,8 @@ OGG_DEV void dpole_quad_tables_body(const DpQuadParams& p, long bx, long n_block
             iv = (var & 1) ? iv + off : iv - off;
         }
         const cplx ep = dp_column(iv, p.g, c);
-        p.col_tab[(var * 2 + 0) * p.n_cols + col] = ep.re;
-        p.col_tab[(var * 2 + 1) * p.n_cols + col] = ep.im;
+        col_tab[(var * 2 + 0) * p.n_cols + col] = ep.re;
+        col_tab[(var * 2 + 1) * p.n_cols + col] = ep.im;
     }
     if (p.words) {
         const long n_words = p.n_chunks * (M * p.rows_per_chunk + 1) * p.n_strips;
@@ -319,9 +321,10 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
     p.n_chunks = n_cell_rows > 0 ? (n_cell_rows + p.rows_per_chunk - 1) / p.rows_per_chunk : 1;
     p.q = q;
     p.ticket = static_cast<unsigned*>(ws);
-    p.row_tab = reinterpret_cast<double*>(static_cast<char*>(ws) + 16);
-    p.col_tab = p.row_tab + NV * p.n_rows;
-    p.words = (arc_form == DP_ARC_LITERAL) ? reinterpret_cast<unsigned long long*>(p.col_tab + NV * 2 * p.n_cols) : nullptr;
+    double* tabs = reinterpret_cast<double*>(static_cast<char*>(ws) + 16);
+    p.row_tab = tabs;
+    p.col_tab = tabs + NV * p.n_rows;
+    p.words = (arc_form == DP_ARC_LITERAL) ? reinterpret_cast<unsigned long long*>(tabs + NV * p.n_rows + NV * 2 * p.n_cols) : nullptr;
     p.dxq = dxq, p.dyq = dyq, p.daq = daq;
     return OGG_OK;
 }
@@ -496,9 +499,11 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
     const bool dy_edge = cell_start && ci == p.g.ni;    // first node column of cell nx: dyq[.][nx]
     const DpConst c = dp_const(p.g);
     const double reps = 1.0 / p.eps;
+    const double* __restrict__ row_tab = p.row_tab;   // written by the tables kernel of this call, read-only here: scalar loads
+    const double* __restrict__ col_tab = p.col_tab;
     cplx ep[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) ep[v] = cplx{p.col_tab[(v * 2 + 0) * p.n_cols + uc], p.col_tab[(v * 2 + 1) * p.n_cols + uc]};
+    for (int v = 0; v < NV; ++v) ep[v] = cplx{col_tab[(v * 2 + 0) * p.n_cols + uc], col_tab[(v * 2 + 1) * p.n_cols + uc]};
 
     const long r0 = chunk * p.rows_per_chunk;                     // band-local first cell row of the chunk
     const long nc = (p.n_cell_rows - r0 < p.rows_per_chunk) ? p.n_cell_rows - r0 : p.rows_per_chunk;   // cell rows of the chunk (>= 0)
@@ -525,7 +530,7 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
             const long row = M * r0 + L + 1;      // band-local lattice row
             double r[NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) r[v] = p.row_tab[v * p.n_rows + row];   // wave-uniform
+            for (int v = 0; v < NV; ++v) r[v] = row_tab[v * p.n_rows + row];   // wave-uniform
             if (ARC == DP_ARC_CHORD) {
                 dq_chord_point<F>(r, ep, c, reps, pend_next.va[0], pend_next.vb[0]);
             } else {
