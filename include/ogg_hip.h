@@ -119,6 +119,13 @@ typedef struct {
 /* Up to 4 lat-lon bands in one launch, axes evaluated in the kernel: lon[i] = lon0 + (i*lenlon)/(ni1-1) (OGG:431, 834). */
 int ogg_latlon_supergrid_multi_dev(int n_bands, const ogg_latlon_band* bands, long ni1, double lon0, double lenlon, double Re,
                                    int metrics, void* stream);
+/* The same fields, the same bits, for launches that carry nothing but lat-lon sub-grids: the unit of work is one ROW of one FIELD and
+ * units are taken in (band, field, row) order, so the chip writes a compact window that sweeps through one array at a time -- the
+ * pattern its HBM write path rewards -- fed from a row table and a column table built by a first small launch in the caller's
+ * workspace (>= ogg_latlon_rows_workspace_bytes bytes of device memory).  Two launches, no allocation. */
+long ogg_latlon_rows_workspace_bytes(int n_bands, const ogg_latlon_band* bands, long ni1);
+int ogg_latlon_supergrid_rows_ws_dev(int n_bands, const ogg_latlon_band* bands, long ni1, double lon0, double lenlon, double Re,
+                                     int metrics, void* workspace, long workspace_bytes, void* stream);
 int ogg_latlon_supergrid_dev(long n_pt_rows, long n_cell_rows, long ni1, const double* lat1d, const double* lon1d, double Re,
                              int metrics, double* x, double* y, double* dx, double* dy, double* area, double* angle,
                              void* stream);

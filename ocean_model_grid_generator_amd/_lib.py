@@ -116,6 +116,8 @@ SIGNATURES = {
     "ogg_monotonic_bounding": [c_long, c_long, c_void_p, c_double],
     "ogg_monotonic_bounding_dev": [c_long, c_long, c_void_p, c_double, c_void_p],
     "ogg_latlon_supergrid_multi_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int, c_void_p],
+    "ogg_latlon_supergrid_rows_ws_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int, c_void_p, c_long,
+                                         c_void_p],
     "ogg_tripolar_pass_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
                               ctypes.POINTER(BipolarBand), c_void_p],
     "ogg_tripolar_pass_events_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
@@ -139,7 +141,8 @@ LONG_GETTERS = {"ogg_abi_sizeof": [c_int],
                 "ogg_bipolar_quad_workspace_bytes": [c_int, c_long, c_long],
                 "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long],
                 "ogg_displaced_pole_grid_workspace_bytes": [c_long, c_long],
-                "ogg_dpole_band_workspace_bytes": [c_int, c_long, c_long]}
+                "ogg_dpole_band_workspace_bytes": [c_int, c_long, c_long],
+                "ogg_latlon_rows_workspace_bytes": [c_int, ctypes.POINTER(LatlonBand), c_long]}
 
 _lib = None
 

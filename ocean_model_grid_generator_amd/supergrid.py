@@ -276,6 +276,7 @@ class Supergrid(object):
         self.pass_events = None  # a list: tripolar_pass() times its launches into it
         self._event_pool = []
         self._pass_args = None
+        self._rows_ws = None
         self._side = None
         self.buf = {}
         self.timings = {}
@@ -452,9 +453,20 @@ class Supergrid(object):
         if self.latlon == "fused":
             bands = self._latlon_bands(only, kinds)
             if bands:
+                import os
                 arr = (L.LatlonBand * len(bands))(*bands)
-                self._timed("latlon_fused", lambda: L.call("ogg_latlon_supergrid_multi_dev", len(bands), arr, ni1, p.lon0, p.lenlon, p.Re,
-                                                           0 if p.skip_metrics else 1, st))
+                if os.environ.get("OGG_LATLON_ROWS", "0") != "0":
+                    # a launch with nothing but lat-lon sub-grids: (field, row)-ordered workgroups fed from row / column tables (an
+                    # option: same bits, and within 4 % of the column-tile kernel either way on the same box)
+                    need = int(L.load().ogg_latlon_rows_workspace_bytes(len(bands), arr, ni1))
+                    if self._rows_ws is None or self._rows_ws.numel() < need:
+                        self._rows_ws = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+                    ws = self._rows_ws
+                    self._timed("latlon_fused", lambda: L.call("ogg_latlon_supergrid_rows_ws_dev", len(bands), arr, ni1, p.lon0, p.lenlon,
+                                                               p.Re, 0 if p.skip_metrics else 1, ws.data_ptr(), ws.numel(), st))
+                else:
+                    self._timed("latlon_fused", lambda: L.call("ogg_latlon_supergrid_multi_dev", len(bands), arr, ni1, p.lon0, p.lenlon,
+                                                               p.Re, 0 if p.skip_metrics else 1, st))
         for s in p.subs:
             b = self.buf[s.name]
             if b["n"] == 0 or not self._selected(s, only, kinds):

@@ -78,6 +78,18 @@ def test_fused_latlon_kernel_is_bit_identical_to_stencil(sg, name, world):
         assert np.array_equal(stencil[f], fused[f]), (f, world)
 
 
+@pytest.mark.parametrize("name", ["r1_cut2", "r2_skip_metrics", "r0.25_even"])
+def test_row_ordered_latlon_kernel_is_bit_identical(sg, name, monkeypatch):
+    """ogg_latlon_supergrid_rows_ws_dev ((field, row)-ordered workgroups fed from tables) against the column-tile kernel."""
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    monkeypatch.setenv("OGG_LATLON_ROWS", "0")
+    tiles = run(sg, plan, 1, latlon="fused")
+    monkeypatch.setenv("OGG_LATLON_ROWS", "1")
+    rows = run(sg, plan, 3, latlon="fused")
+    for f in FIELDS:
+        assert np.array_equal(tiles[f], rows[f]), f
+
+
 def run_pass_mode(sg, plan, world=1):
     import torch
     out = []
