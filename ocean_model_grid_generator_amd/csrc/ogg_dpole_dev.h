@@ -178,8 +178,19 @@ OGG_DEV unsigned lb_incoming(const unsigned long long* row_words, long s, unsign
         }
         unsigned m0 = have ? (unsigned)(w & 0xffffull) & all : 0u;
         unsigned m1 = have ? (unsigned)((w >> 16) & 0xffffull) & all : all;
-        map_scan(m0, m1);
-        const unsigned b0 = __shfl(m0, 63), b1 = __shfl(m1, 63);   // the block's composed map
+        // usually at most one strip of the block holds anything but the identity (strip 0, or the strip where the longitude crosses
+        // the cut): its map is the block's; otherwise compose them all
+        const unsigned long long nonid = __ballot(m0 != 0u || m1 != all);
+        unsigned b0, b1;
+        if (nonid == 0ull) {
+            b0 = 0u, b1 = all;
+        } else if ((nonid & (nonid - 1ull)) == 0ull) {
+            const int src = 63 - __builtin_clzll(nonid);
+            b0 = __shfl(m0, src), b1 = __shfl(m1, src);
+        } else {
+            map_scan(m0, m1);
+            b0 = __shfl(m0, 63), b1 = __shfl(m1, 63);   // the block's composed map
+        }
         const unsigned n0 = map_apply(b0, b1, t0), n1 = map_apply(b0, b1, t1);
         t0 = n0, t1 = n1;
     }
@@ -405,8 +416,8 @@ OGG_DEV void dq_probe_pair(int k, const double* r, const cplx* ep, double& ra, d
 }
 
 #ifndef OGG_DQ_UNROLL
-#define OGG_DQ_UNROLL 1   // pairs evaluated one after the other: interleaving the libm calls of several probes costs registers
-#endif
+#define OGG_DQ_UNROLL 8   // the probe loop fully unrolled (no compare-selects to pick a probe's operands and result slots): 233 VGPRs
+#endif                    // like the rolled loop's 238, 2.0 -> 1.67 ms for config 4; 1 = rolled
 
 // phase 1 of the literal form: all probes of this lane's lattice point (OGG:522-526, 454-466), ONE at a time (two projections
 // in flight need 60 more registers than one)
@@ -557,7 +568,9 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
                 }
                 // lane 0's column belongs to the strip on the left (its state is the incoming state); columns past the row end: identity
                 if ((lane == 0 && u != 0) || !valid) f0 = 0u, f1 = ALL;
-                map_scan(f0, f1);
+                // almost every strip of almost every row holds identity maps only (the constant ones sit at column 0 and where the
+                // longitude crosses the cut): the scan is then the identity too
+                if (__ballot(f0 != 0u || f1 != ALL) != 0ull) map_scan(f0, f1);
                 inc0_next = f0, inc1_next = f1;
                 if (lane == 63) lb_publish(words + (L + 1) * p.n_strips + strip, f0, f1);
             }
