@@ -290,10 +290,16 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     }
     if (int e = mark(1)) return e;
     if (launch_b) {
-        // dispatch order of the compute roles: the quadrature strips first (long, issue-bound waves), the meshes last -- their short
-        // workgroups fill the slots the draining strips leave (2 % faster than meshes first at 1/8 degree, with or without a
-        // displaced-pole cap; scripts/order_sweep.py).  OGG_PASS_ORDER = permutation of "01234" (ROLE_* ids) for experiments
-        static const int dflt[N_ROLES] = {ROLE_BP_FAST, ROLE_BP_GUARD, ROLE_DP_QUAD, ROLE_BP_MESH, ROLE_DP_MESH};
+        // dispatch order of the compute roles.  A big launch (>= ~2 M quadrature cells: a whole 1/8 degree cap or half of it) puts the
+        // quadrature strips first (long, issue-bound waves) and the meshes last -- their short workgroups fill the slots the draining
+        // strips leave: 2 % faster than meshes first at 1/8 degree on one GPU.  A small launch (a quarter of that cap or less) no
+        // longer fills the chip; there the latency-bound meshes want to start first: 3.5 % faster at 1/4, 7 % at 1/8 of the cap
+        // (scripts/order_sweep.py, scripts/rank_sweep.py).  OGG_PASS_ORDER = permutation of "01234" (ROLE_* ids) for experiments
+        static const int quad_first[N_ROLES] = {ROLE_BP_FAST, ROLE_BP_GUARD, ROLE_DP_QUAD, ROLE_BP_MESH, ROLE_DP_MESH};
+        static const int mesh_first[N_ROLES] = {ROLE_BP_MESH, ROLE_DP_MESH, ROLE_BP_GUARD, ROLE_BP_FAST, ROLE_DP_QUAD};
+        const double quad_cells = (have_quad ? (double)cap->n_cell_rows * (double)cap->Ni : 0.0) +
+                                  ((have_dquad && !dq_literal) ? (double)scap->n_cell_rows * (double)scap->Ni : 0.0);
+        const int* dflt = quad_cells >= 2.0e6 ? quad_first : mesh_first;
         const char* ord = getenv("OGG_PASS_ORDER");
         for (int k = 0; k < N_ROLES; ++k)
             B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : dflt[k];
