@@ -80,8 +80,15 @@ class DeviceToFile(object):
             self.bytes += cnt * 8
 
     def finish(self):
+        """Wait for every pending write (re-raising the first failure) and stop the writer threads."""
+        first = None
         for f in self.busy:
             if f is not None:
-                f.result()
+                try:
+                    f.result()
+                except Exception as exc:   # keep draining: the threads must be done before the caller closes the file
+                    first = first or exc
         self.busy = [None] * len(self.ring)
         self.pool.shutdown(wait=True)
+        if first is not None:
+            raise first

@@ -641,6 +641,7 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
     for s in plan.subs:
         print("Generating %s sub-grid: %d rows x %d columns" % (s.name, s.nj1, plan.Ni + 1))
     g.run_pass()
+    g.check_lookback_flags()
     if not skip_metrics:   # the reference's CHECK_metrics lines (OGG:1017,1070,1112,1157,1172) from sums taken on the device
         labels = {"Merc": "CHECK_metrics: % errors in (area, lat arc, lon arc)", "BP": "CHECK_metrics_hquad: % errors in (area, lat arc, lon arc1, lon arc2)",
                   "SO": "CHECK_metrics_MIDAS: % errors in (area, lat arc, lon arc)"}

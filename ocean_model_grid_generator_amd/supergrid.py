@@ -694,6 +694,19 @@ class Supergrid(object):
         return out
 
     # -- results ---------------------------------------------------------------------------------------------
+    def check_lookback_flags(self):
+        """Raise if a displaced-pole kernel of the last pass gave up waiting for a strip map (its results would be invalid; the wait
+        is bounded so that a launch always drains -- never observed).  Synchronises the stream."""
+        for s in self.plan.subs:
+            b = self.buf[s.name]
+            if s.kind != "dpole" or b["n"] == 0:
+                continue
+            for off, what in ((0, "mesh"), (b["ws_mesh_bytes"], "quadrature")):
+                flag = ctypes.c_int(0)
+                L.call("ogg_workspace_error_flag_dev", b["ws"].data_ptr() + off, ctypes.byref(flag), self._stream())
+                if flag.value != 0:
+                    raise L.OggHipError(L.OGG_EHIP, "displaced-pole %s: a look-back wait timed out (flag %d)" % (what, flag.value))
+
     def south_cut(self):
         """plan.south_cut() with the cap's latitudes read from the device when --south_cutoff_ang needs them (world 1)."""
         first = self.plan.subs[0]
@@ -759,14 +772,16 @@ class Supergrid(object):
             ds.write_header(fd)
             os.pwrite(fd, b"tile1".ljust(255, b"\0"), ds.var_begin("tile"))
             stream = nc_stream.DeviceToFile(fd, self.device)
-            for name, f, _, _ in spec:
-                off = ds.var_begin(name)
-                for s, lo, hi in self._pieces(cut, f in ("x", "y", "dx", "angle_dx")):
-                    if hi > lo:
-                        t = self.buf[s.name][f][lo:hi]
-                        stream.put(t, off)
-                        off += t.numel() * 8
-            stream.finish()
+            try:
+                for name, f, _, _ in spec:
+                    off = ds.var_begin(name)
+                    for s, lo, hi in self._pieces(cut, f in ("x", "y", "dx", "angle_dx")):
+                        if hi > lo:
+                            t = self.buf[s.name][f][lo:hi]
+                            stream.put(t, off)
+                            off += t.numel() * 8
+            finally:
+                stream.finish()   # also after an error: no writer thread may outlive the file descriptor
         finally:
             os.close(fd)
         return stream.bytes, time.perf_counter() - t0

@@ -101,6 +101,7 @@ def run_pass_mode(sg, plan, world=1):
         g.launch = "pass"
         g.step()
         torch.cuda.synchronize()
+        g.check_lookback_flags()
         out.append(g.bands_to_host())
     return sg.stitch(plan, out)
 
