@@ -308,7 +308,7 @@ class Supergrid(object):
                     b["ws"] = torch.empty(b["ws_bytes"], dtype=torch.uint8, device=self.device)
                 elif s.kind == "dpole":   # one workspace for the pass (mesh words + quadrature tables and words); the stand-alone
                     b["ws_bytes"] = int(L.load().ogg_dpole_band_workspace_bytes(4, plan.Ni, n))   # kernels use its two parts
-                    b["ws"] = torch.empty(max(b["ws_bytes"], 16), dtype=torch.uint8, device=self.device)
+                    b["ws"] = torch.zeros(max(b["ws_bytes"], 16), dtype=torch.uint8, device=self.device)
                     b["ws_mesh_bytes"] = (int(L.load().ogg_displaced_pole_grid_workspace_bytes(plan.Ni, n)) + 255) // 256 * 256
                 self.buf[s.name] = b
 
@@ -701,7 +701,7 @@ class Supergrid(object):
             b = self.buf[s.name]
             if s.kind != "dpole" or b["n"] == 0:
                 continue
-            for off, what in ((0, "mesh"), (b["ws_mesh_bytes"], "quadrature")):
+            for off, what in ((0, "mesh"),) + (() if self.plan.skip_metrics else ((b["ws_mesh_bytes"], "quadrature"),)):
                 flag = ctypes.c_int(0)
                 L.call("ogg_workspace_error_flag_dev", b["ws"].data_ptr() + off, ctypes.byref(flag), self._stream())
                 if flag.value != 0:
