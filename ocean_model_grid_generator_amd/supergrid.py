@@ -239,7 +239,10 @@ class SupergridPlan(object):
         """Rows removed at the south end of the stitched grid (stitching drops the cap's last row, so a cap that is cut away
         altogether takes nj1 - 1 stitched rows with it)."""
         c_sc, c_so, gone = self.south_cut(sc_y0)
-        return (self.subs[0].nj1 - 1 + c_so) if gone else c_sc
+        if not gone:
+            return c_sc
+        so = next(s for s in self.subs if s.name == "SO")
+        return self.subs[0].nj1 - 1 + min(c_so, so.nj1 - 1)   # a cut beyond the Southern Ocean piece leaves none of its rows (OGG:1306-1311)
 
     @property
     def nyp(self):

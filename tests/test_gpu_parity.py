@@ -415,8 +415,8 @@ def _row_tolerances(got, field):
     names = [s for s in ("BP", "Merc", "SO", "SC") if s in got["sub"]]
     for pos, name in enumerate(names):
         rows = _piece(got["sub"], name, k).shape[0]
-        if field in ("x", "y", "dx") and pos > 0:
-            rows -= 1     # its last row was replaced by the first row of the piece above
+        if field in ("x", "y", "dx") and pos > 0 and rows > 0:
+            rows -= 1     # its last row was replaced by the first row of the piece above (a piece cut away altogether has none)
         kind = "bipolar" if name == "BP" else "latlon"
         if name == "SC" and np.ptp(_piece(got["sub"], "SC", 0), axis=0).max() > 0:   # longitudes vary along j: displaced pole
             kind = "dpole"

@@ -149,3 +149,68 @@ def test_tripolar_pass_random_plans(hip, seed):
         assert "Ooops" in str(exc) or "repeated values" in str(exc)
         return
     _check_supergrid(ga, want, "random_plan_%d" % seed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_main_random_flags_pass_path_vs_function_level_and_oracle(hip, seed):
+    """main() with randomly drawn flag sets -- resolution, --ensure_nj_even, displaced pole by radius or by latitude (or none),
+    south cuts by row or by angle, --match_dy, --no_south_cap, --exfracdp, latitude overrides, --skip_metrics -- through the
+    device-resident pass against the function-level path (bitwise, bipolar angle_dx excepted) and against the oracle; flag sets
+    the reference's own guards reject must be rejected with the same text."""
+    import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+    from test_gpu_pipeline import _same_as_function_level, FIELDS
+    rng = np.random.default_rng(7000 + seed)
+    flags = dict(inverse_resolution=float(rng.choice([0.25, 0.5, 0.75, 1.0])), ensure_nj_even=bool(rng.integers(0, 2)))
+    pole = int(rng.integers(0, 3))
+    if pole == 1:
+        flags["r_dp"] = float(rng.choice([0.1, 0.2, 0.3]))
+    elif pole == 2:
+        flags.update(lat_dp=float(rng.uniform(-88.0, -84.0)), lon_dp=float(rng.uniform(0.0, 359.0)))
+    if pole and rng.integers(0, 2):
+        flags["exfracdp"] = float(rng.choice([0.0, 0.3, 0.49, 0.6]))
+    cut = int(rng.integers(0, 4))
+    if cut == 1:
+        flags["south_cutoff_row"] = int(rng.integers(1, 12))
+    elif cut == 2 and flags["inverse_resolution"] <= 0.5:
+        flags["south_cutoff_row"] = int(rng.integers(20, 45))      # may consume the whole cap
+    elif cut == 3:
+        flags["south_cutoff_ang"] = float(rng.uniform(-86.0, -79.0))
+    if rng.integers(0, 3) == 0:
+        flags["match_dy"] = [["bp"], ["so"], ["bp", "so"], ["bp", "so", "p125sc"]][int(rng.integers(0, 4))]
+    if rng.integers(0, 5) == 0:
+        flags["no_south_cap"] = True
+    if rng.integers(0, 4) == 0:
+        flags["south_ocean_lower_lat"] = float(rng.uniform(-84.0, -75.0))
+    if rng.integers(0, 6) == 0:
+        flags["skip_metrics"] = True
+    if seed >= 10:   # (the first ten seeds keep the flag sets they were first run with)
+        extra = int(rng.integers(0, 8))
+        if extra == 0:
+            flags["grids"] = ["bipolar", "mercator", "so"]
+        elif extra == 1:
+            flags["grids"] = ["mercator", "so", "sc"]
+        elif extra == 2:
+            lat = float(rng.uniform(62.0, 68.0))
+            flags.update(bipolar_lower_lat=lat, mercator_upper_lat=lat)
+        elif extra == 3:
+            flags["mercator_lower_lat"] = float(rng.uniform(-70.0, -60.0))
+        elif extra == 4 and not pole:
+            flags.update(inverse_resolution=2.0, enhanced_equatorial=4)
+            flags.pop("south_cutoff_ang", None)
+        elif extra == 5:
+            flags["shift_equator_to_u_point"] = False
+    r = flags["inverse_resolution"]
+    oflags = {k: v for k, v in flags.items() if k != "inverse_resolution"}
+    try:
+        want = orc.make_supergrid(r, skip_doughnut_rows=True, **oflags)
+    except BaseException as exc:   # rejected by the reference's own logic (guards, or a cut that needs a cap that is not there)
+        with pytest.raises(BaseException) as ei:
+            ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, **flags)
+        if isinstance(exc, Exception) and "Ooops" in str(exc):
+            assert str(ei.value) == str(exc), flags
+        return
+    got = ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, **flags)
+    ref = ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, path="functions", **flags)
+    ref = dict(ref, sub={k: dict(zip(FIELDS, v)) for k, v in ref["sub"].items()})
+    _same_as_function_level(got, ref, str(flags))
+    _check_supergrid(got, want, "random_flags_%d" % seed)
