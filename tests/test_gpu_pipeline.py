@@ -117,6 +117,52 @@ def test_tripolar_pass_is_bit_identical_to_separate_kernels(sg, name, world):
         assert np.array_equal(kernels[f], fused[f], equal_nan=False), (f, world)
 
 
+@pytest.mark.parametrize("order,arc", [(2, "literal"), (2, "chord"), (4, "literal"), (4, "chord")])
+def test_supergrid_pass_southern_cap_alone_matches_function_level(hip, order, arc):
+    """ogg_supergrid_pass_dev with nothing but a displaced-pole band (no lat-lon bands, no bipolar cap), both quadrature orders and
+    both arc forms, band in the middle of the cap: the same bits as ogg_displaced_pole_grid_angle_ws_dev +
+    ogg_displaced_pole_metrics_quad_form_ws_dev."""
+    import ctypes
+    import torch
+    from ocean_model_grid_generator_amd import _lib as L
+    lib = L.load()
+    Ni, Nj, j0, n = 200, 30, 7, 11
+    form = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[arc]
+    geo = (-300.0, -78.0, 95.0, 0.27)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fields():
+        return {f: torch.full(shp, float("nan"), dtype=torch.float64, device="cuda:0")
+                for f, shp in (("x", (n, Ni + 1)), ("y", (n, Ni + 1)), ("angle", (n, Ni + 1)), ("dx", (n, Ni)), ("dy", (n, Ni + 1)), ("area", (n, Ni)))}
+
+    a, b = fields(), fields()
+    wsb = int(lib.ogg_dpole_band_workspace_bytes(order, Ni, n))
+    ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda:0")
+    band = L.DpoleBand()
+    band.Ni, band.Nj, band.lon0, band.lat0, band.lon_dp, band.r_dp, band.Re = Ni, Nj, geo[0], geo[1], geo[2], geo[3], 6371.0e3
+    band.order, band.arc_form, band.j0, band.n_pt_rows, band.n_cell_rows = order, form, j0, n, n
+    for f in a:
+        setattr(band, f, a[f].data_ptr())
+    band.workspace, band.workspace_bytes = ws.data_ptr(), wsb
+    L.call("ogg_supergrid_pass_dev", 0, (L.LatlonBand * 1)(), Ni + 1, geo[0], 360.0, 6371.0e3, 1, None, ctypes.byref(band), None, None, st)
+    mws = int(lib.ogg_displaced_pole_grid_workspace_bytes(Ni, n))
+    qws = int(lib.ogg_displaced_pole_quad_workspace_bytes(order, Ni, n))
+    w1 = torch.zeros(mws, dtype=torch.uint8, device="cuda:0")
+    w2 = torch.zeros(qws, dtype=torch.uint8, device="cuda:0")
+    L.call("ogg_displaced_pole_grid_angle_ws_dev", Ni, Nj, geo[0], geo[1], geo[2], geo[3], j0, n, b["x"].data_ptr(), b["y"].data_ptr(),
+           b["angle"].data_ptr(), w1.data_ptr(), mws, st)
+    L.call("ogg_displaced_pole_metrics_quad_form_ws_dev", form, order, Ni, Nj, geo[0], geo[1], geo[2], geo[3], 6371.0e3, j0, n, n,
+           b["dx"].data_ptr(), b["dy"].data_ptr(), b["area"].data_ptr(), w2.data_ptr(), qws, st)
+    torch.cuda.synchronize()
+    for f in a:
+        assert not bool(torch.isnan(a[f]).any()), f
+        assert torch.equal(a[f], b[f]), (order, arc, f)
+    want = orc.displacedPoleCap_metrics_quad(order, Ni, Nj, geo[0], geo[1], geo[2], geo[3])
+    for f, w in zip(("dx", "dy", "area"), want):
+        w = w[j0:j0 + n]
+        assert np.abs(a[f].cpu().numpy() - w).max() <= 1e-9 * np.abs(w).max(), (order, arc, f)
+
+
 def test_tripolar_pass_full_size_r8_bitwise(sg):
     """1/8 degree, the benchmark workload: the fused pass against one launch per sub-grid and phase, compared on the device."""
     import torch
