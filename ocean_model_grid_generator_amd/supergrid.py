@@ -720,47 +720,59 @@ class Supergrid(object):
         return self.plan.south_cut(y0)
 
     def _pieces(self, cut, point_rows):
-        """[(sub-grid, first row, end row)] of a stitched field, south -> north (OGG:1315-1365): fields on point rows (x, y, dx,
-        angle_dx) drop the last row of every piece but the northernmost; dy and area (cell rows) are concatenated whole.  cut: the
-        triple of south_cut().  World 1 (the whole sub-grid is this rank's band)."""
-        assert self.world == 1
+        """This rank's pieces of a stitched field, south -> north, as [(sub-grid, first band row, end band row, row of the stitched
+        field where the piece starts)], and the field's total row count (OGG:1315-1365): fields on point rows (x, y, dx, angle_dx)
+        drop the last row of every sub-grid but the northernmost; dy and area (cell rows) are concatenated whole.  cut: the triple
+        of plan.south_cut().  Every band of every rank maps to ONE contiguous range of stitched rows."""
         c_sc, c_so, gone = cut
         subs = [s for s in self.plan.subs if not (s.name == "SC" and gone)]
-        out = []
+        out, off = [], 0
         for k, s in enumerate(subs):
             b = self.buf[s.name]
-            lo = c_sc if s.name == "SC" else (c_so if (s.name == "SO" and gone) else 0)
-            if point_rows:
-                hi = b["n"] - (0 if k == len(subs) - 1 else 1)
-            else:
-                hi = b["n_cell"]
-            out.append((s, lo, max(hi, lo)))
-        return out
+            first = c_sc if s.name == "SC" else (c_so if (s.name == "SO" and gone) else 0)     # first kept row of the sub-grid
+            last = (s.nj1 - (0 if k == len(subs) - 1 else 1)) if point_rows else s.nj1 - 1     # end of its kept rows
+            kept = max(last - first, 0)
+            r_lo, r_hi = b["lo"], (b["hi"] if point_rows else b["lo"] + b["n_cell"])             # this rank's rows of it
+            lo, hi = max(r_lo, first), min(r_hi, last)
+            if hi > lo:
+                out.append((s, lo - b["lo"], hi - b["lo"], off + (lo - first)))
+            off += kept
+        return out, off
 
     def stitched_rows(self, cut):
         """nyp of the stitched grid"""
-        return sum(hi - lo for _, lo, hi in self._pieces(cut, True))
+        return self._pieces(cut, True)[1]
 
     def stitched_column(self, field, col, cut, only=None):
-        """One column of a stitched field (or of one sub-grid) as a host array: what main()'s guards and description need."""
+        """One column of a stitched field (or of one sub-grid) as a host array: what main()'s guards and description need.  World 1."""
+        assert self.world == 1
         torch = self.torch
         if only is not None:
             b = self.buf[only]
             return b[field][: b["n"], col].cpu().numpy()
-        parts = [self.buf[s.name][field][lo:hi, col] for s, lo, hi in self._pieces(cut, field in ("x", "y", "dx", "angle_dx"))]
-        return torch.cat(parts).cpu().numpy()
+        parts = [self.buf[s.name][field][lo:hi, col] for s, lo, hi, _ in self._pieces(cut, field in ("x", "y", "dx", "angle_dx"))[0]]
+        return torch.cat(parts).cpu().numpy() if parts else np.zeros(0)
 
-    def write_nc(self, fnam, cut, description=None, history=None, source=None, no_changing_meta=None):
+    def write_nc(self, fnam, cut, description=None, history=None, source=None, no_changing_meta=None, create=None, barrier=None):
         """write_nc of OGG:773-829 for the fields in HBM: the reference's layout (dimensions nyp, nxp, ny, nx, string(255); variables
         tile, y, x, dy, dx, area, angle_dx in that order; NetCDF-3 64-bit offset), every band streamed from the device into its byte
-        range of the file (nc_stream).  Returns (bytes streamed, seconds)."""
+        range of the file (nc_stream).  Band-sharded runs write ONE file together: the rank with ``create`` (default: rank 0) writes
+        the header and extends the file to its final size, then -- after ``barrier()`` (default: torch.distributed.barrier when a
+        process group exists and world > 1) -- every rank streams its own bands to their offsets; no gather.  Returns (bytes this
+        rank streamed, seconds)."""
         import os
         import time
         from . import nc_stream, netcdf3
         t0 = time.perf_counter()
         nyp, nx = self.stitched_rows(cut), self.plan.Ni
         ny = nyp - 1
-        print("   Writing netcdf file with ny,nx= ", ny, nx)
+        create = (self.rank == 0) if create is None else create
+        if barrier is None:
+            barrier = lambda: None   # noqa: E731
+            if self.world > 1 and self.halo == "rccl":
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    barrier = dist.barrier
         gatts = []
         if not no_changing_meta:
             gatts = [("history", history or ""), ("description", description or ""), ("source", source or "")]
@@ -770,23 +782,28 @@ class Supergrid(object):
                 ("dx", "dx", ("nyp", "nx"), "meters"), ("area", "area", ("ny", "nx"), "m2"), ("angle_dx", "angle_dx", ("nyp", "nxp"), "degrees"))
         for name, _, dims, units in spec:
             ds.decl_var(name, netcdf3.NC_DOUBLE, dims, [("units", units)])
-        fd = os.open(fnam, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+        if create:
+            print("   Writing netcdf file with ny,nx= ", ny, nx)
+            fd = os.open(fnam, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+            try:
+                ds.write_header(fd)
+                os.pwrite(fd, b"tile1".ljust(255, b"\0"), ds.var_begin("tile"))
+            finally:
+                os.close(fd)
+        barrier()   # the file exists at its final size
+        fd = os.open(fnam, os.O_RDWR)
         try:
-            ds.write_header(fd)
-            os.pwrite(fd, b"tile1".ljust(255, b"\0"), ds.var_begin("tile"))
             stream = nc_stream.DeviceToFile(fd, self.device)
             try:
                 for name, f, _, _ in spec:
-                    off = ds.var_begin(name)
-                    for s, lo, hi in self._pieces(cut, f in ("x", "y", "dx", "angle_dx")):
-                        if hi > lo:
-                            t = self.buf[s.name][f][lo:hi]
-                            stream.put(t, off)
-                            off += t.numel() * 8
+                    row_bytes = (nx + 1 if f in ("x", "y", "dy", "angle_dx") else nx) * 8
+                    for s, lo, hi, row0 in self._pieces(cut, f in ("x", "y", "dx", "angle_dx"))[0]:
+                        stream.put(self.buf[s.name][f][lo:hi], ds.var_begin(name) + row0 * row_bytes)
             finally:
                 stream.finish()   # also after an error: no writer thread may outlive the file descriptor
         finally:
             os.close(fd)
+        barrier()   # every rank's bytes are in the file
         return stream.bytes, time.perf_counter() - t0
 
     def bands_to_host(self):

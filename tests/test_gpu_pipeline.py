@@ -90,6 +90,33 @@ def test_row_ordered_latlon_kernel_is_bit_identical(sg, name, monkeypatch):
         assert np.array_equal(tiles[f], rows[f]), f
 
 
+@pytest.mark.parametrize("name", ["r1_cut2", "r0.5_dp", "r2_skip_metrics"])
+@pytest.mark.parametrize("world", [2, 5])
+def test_band_sharded_ranks_write_one_netcdf_file(sg, name, world, tmp_path):
+    """Every rank of a band-sharded run streams its own bands into ONE NetCDF file at their byte offsets (rank 0 writes the header;
+    no gather): the file is byte-identical to the one a single rank writes."""
+    import torch
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    one = sg.Supergrid(plan, device="cuda:0")
+    one.step()
+    cut = one.south_cut()
+    one.write_nc(str(tmp_path / "one.nc"), cut, no_changing_meta=True)
+    ranks = [sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo="recompute") for r in range(world)]
+    for g in ranks:
+        g.step()
+    torch.cuda.synchronize()
+    for g in ranks:      # rank 0 first: it creates the file (in a real run a barrier stands here)
+        g.write_nc(str(tmp_path / "many.nc"), cut, no_changing_meta=True)
+    a, b = open(tmp_path / "one.nc", "rb").read(), open(tmp_path / "many.nc", "rb").read()
+    assert len(a) == len(b) and a == b
+    got = sg.stitch(plan, [one.bands_to_host()])
+    from scipy.io import netcdf_file
+    nc = netcdf_file(str(tmp_path / "many.nc"), "r", mmap=False)
+    for f in FIELDS:
+        assert np.array_equal(nc.variables[f][:], got[f]), f
+    nc.close()
+
+
 def run_pass_mode(sg, plan, world=1):
     import torch
     out = []
