@@ -201,11 +201,29 @@ class SupergridPlan(object):
         self.Nj_scap = Nj_scap
         self.lat0_SO, self.latUp_SO = lat0_SO, latUp_SO
         self.subs = [s for s in (sc, so, merc, bp) if s is not None]  # south -> north
+        # Rows that --south_cutoff_row / _ang remove from the stitched grid (OGG:1268-1313) are not generated when the cut is known from the
+        # sizes alone -- by row always; by angle on a regular cap, whose latitudes are an axis formula -- just as the doughnut rows are not
+        # (OM4: 82 of the displaced-pole cap's 143 kept rows).  The cut of a displaced-pole cap by ANGLE needs the cap's latitudes and is
+        # applied after the pass (south_cut(sc_y0) / Supergrid.south_cut()).
+        self.cut_applied = None
+        by_angle_later = south_cutoff_row <= 0 and south_cutoff_ang > -90 and sc is not None and sc.kind != "latlon"
+        if (south_cutoff_row > 0 or south_cutoff_ang > -90) and not by_angle_later:
+            c_sc, c_so, gone = self.south_cut()
+            if gone:
+                self.subs = [s for s in self.subs if s.name != "SC"]
+                so.row0, so.nj1 = so.row0 + min(c_so, so.nj1), max(so.nj1 - c_so, 0)
+                if so.nj1 == 0:      # a cut beyond the Southern Ocean piece: nothing of it is stitched (its [jcut:] slice is empty)
+                    self.subs = [s for s in self.subs if s.name != "SO"]
+            elif c_sc > 0:
+                sc.row0, sc.nj1 = sc.row0 + c_sc, sc.nj1 - c_sc
+            self.cut_applied = (c_sc, c_so, gone)
 
     def south_cut(self, sc_y0=None):
         """(rows cut from the southern cap, rows cut from the Southern Ocean piece, cap removed) by --south_cutoff_row / _ang,
         OGG:1268-1313, including the parity bumps of --ensure_nj_even.  ``sc_y0``: column 0 of the cap's latitudes, needed for
-        --south_cutoff_ang only."""
+        --south_cutoff_ang only.  (0, 0, False) once the plan has applied the cut to its own sub-grid sizes (``cut_applied``)."""
+        if getattr(self, "cut_applied", None) is not None:
+            return 0, 0, False
         first = self.subs[0]
         has_sc = first.name == "SC"
         n_sc = first.nj1 if has_sc else 0

@@ -75,7 +75,8 @@ def test_plan_sizes_and_cuts_follow_the_oracle(seed):
         rows["SO"] = max(rows["SO"] - c_so, 0)
     elif "SC" in rows:
         rows["SC"] -= c_sc
-    assert rows == {k: v[1].shape[0] for k, v in want["sub"].items()}, (flags, rows)
+    # (a sub-grid the cut removes altogether is an empty piece in the reference and simply absent from the plan)
+    assert {k: v for k, v in rows.items() if v} == {k: v[1].shape[0] for k, v in want["sub"].items() if v[1].shape[0]}, (flags, rows)
     assert plan.nyp == want["y"].shape[0] and plan.cells == want["area"].size, flags
     for s in plan.subs:
         if s.kind == "bipolar":     # (the mesh's first row reproduces the joint latitude to an ulp of the projection, OGG:41)
