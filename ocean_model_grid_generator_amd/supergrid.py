@@ -65,7 +65,8 @@ class SubGridPlan(object):
 class SupergridPlan(object):
     """Host-side size logic of main() (OGG:969-1197, 1268-1313) for its whole flag surface: sub-grid selection (--grids), latitude
     overrides, --enhanced_equatorial (the spliced 1-D axis is built on the host, OGG:349-428, and handed to the lat-lon kernel as an
-    explicit axis), --match_dy, --ensure_nj_even, the displaced pole, the doughnut and the south cuts (applied at stitch time).
+    explicit axis), --match_dy, --ensure_nj_even, the displaced pole, the doughnut and the south cuts (rows a cut removes are not
+    generated when the cut follows from the sizes alone; a cut by angle of a displaced-pole cap is applied at stitch time).
     Needs the GPU unless ``mercator_axis`` is given: y* and the Mercator axis come from the device kernels, exactly as main() reads
     the joint latitudes off phiMerc."""
 
