@@ -162,6 +162,49 @@ __global__ void bipolar_projection_kernel(long n, const double* __restrict__ lam
     if (hj) hj[k] = h_j;
 }
 
+// ---- the two inverse tangents of the mesh kernel -----------------------------------------------------------------------------------
+// ocml's atan and atan2 spend two thirds of their instructions on what this kernel never feeds them (infinities, NaNs, signed zeros,
+// |x| > 1, range selection): 83 and 114 instructions for 35 and 44 of fp64 arithmetic.
+//
+// atan(u) for 0 <= u <= 0.3 -- u = rp tan(chi/2) <= rp = tan(13 degrees) = 0.23 for every cap main() builds -- from 14 terms of the odd
+// Taylor series in Horner form (the first omitted term is below 5e-18 relative): 0.57 ulp at worst (validated on the host against
+// atanl on 3e7 arguments; glibc: 0.52), 19 instructions.  A wave with any larger argument (a cap that starts south of 56.6 degrees)
+// takes ocml's atan, behind one ballot.
+OGG_DEV double atan_cap(double u) {
+    if (__builtin_expect(__ballot(!(u <= 0.3)) != 0ull, 0)) return atan(u);
+    const double z = u * u;
+    double p = -1.0 / 29.0;
+    p = fma(p, z, 1.0 / 27.0), p = fma(p, z, -1.0 / 25.0), p = fma(p, z, 1.0 / 23.0), p = fma(p, z, -1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0), p = fma(p, z, -1.0 / 17.0), p = fma(p, z, 1.0 / 15.0), p = fma(p, z, -1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0), p = fma(p, z, -1.0 / 9.0), p = fma(p, z, 1.0 / 7.0), p = fma(p, z, -1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    return fma(-(u * z), p, u);
+}
+
+// atan2(y, x) for the fused angle_x (finite arguments): octant reduction with ONE reciprocal -- r = (mn - mx) / (mn + mx) when
+// mn / mx > tan(pi/8), mn / mx otherwise, so |r| <= tan(pi/8) -- and 17 terms of the odd series: 6e-16 rad at worst (host, 3e7
+// arguments), which is 3e-14 degrees where the fused angle is held to 1e-10 (it already takes cos(phi) algebraically).  atan2(0, 0) = 0
+// like numpy's arctan2(+0, +0).
+OGG_DEV double atan2_angle(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const bool big = mn > 0.41421356237309503 * mx;
+    const double num = big ? mn - mx : mn, den = big ? mn + mx : mx;
+    const double r = num * rcp_nr(den);
+    const double z = r * r;
+    double p = 1.0 / 35.0;
+    p = fma(p, z, -1.0 / 33.0), p = fma(p, z, 1.0 / 31.0), p = fma(p, z, -1.0 / 29.0), p = fma(p, z, 1.0 / 27.0);
+    p = fma(p, z, -1.0 / 25.0), p = fma(p, z, 1.0 / 23.0), p = fma(p, z, -1.0 / 21.0), p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, -1.0 / 17.0), p = fma(p, z, 1.0 / 15.0), p = fma(p, z, -1.0 / 13.0), p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, -1.0 / 9.0), p = fma(p, z, 1.0 / 7.0), p = fma(p, z, -1.0 / 5.0), p = fma(p, z, 1.0 / 3.0);
+    double a = fma(-(r * z), p, r);
+    a = big ? 0.78539816339744830962 + a : a;          // atan(mn / mx) in [0, pi/4]
+    a = (ay > ax) ? 1.57079632679489661923 - a : a;
+    a = (x < 0.0) ? 3.14159265358979323846 - a : a;
+    a = (mx == 0.0) ? 0.0 : a;
+    return copysign(a, y);
+}
+
 // ---- mesh builder (OGG:103-122) fused with angle_x (OGG:719-729), rows j0 .. j0+nrows-1 ------------------------
 // A wave owns 62 output columns plus one halo column on either side, so the i-1 / i+1 neighbours that angle_x needs
 // come from wave shuffles and every lane does the same work.  Row-only factors are computed once per row of the
@@ -218,7 +261,7 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
         const double m1 = 1 - A, p1 = 1 + A;
         const double t = (m1 > 0.0) ? m1 * rsqrt_nr(m1 * p1) : 0.0;                    // sqrt((1-A)/(1+A)) == tan(acos(A)/2), OGG:69-70
         const double u = rp * t;
-        const double phi = 90 - div_pi180(2 * atan(u));
+        const double phi = 90 - div_pi180(2 * atan_cap(u));
         if (out) {
             lams[jl * ni1 + i] = lam;
             phis[jl * ni1 + i] = phi;
@@ -237,11 +280,11 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
             const double cy = (2 * u) / (1 + u * u);
             double a;
             if (i == 0)
-                a = atan2(yr - phi, (xr - lam) * cy);
+                a = atan2_angle(yr - phi, (xr - lam) * cy);
             else if (i == Ni)
-                a = atan2(phi - yl, (lam - xl) * cy);
+                a = atan2_angle(phi - yl, (lam - xl) * cy);
             else
-                a = atan2(yr - yl, (xr - xl) * cy);
+                a = atan2_angle(yr - yl, (xr - xl) * cy);
             if (out) angle[jl * ni1 + i] = div_pi180(a);
         }
     }
