@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libogg_hip.so")
+# OGG_LIB_PATH: another build of the same library (A/B timing of two builds on one box, scripts/ab_libs.sh); it must export the same ABI
+LIB_PATH = os.environ.get("OGG_LIB_PATH") or os.path.join(_HERE, "csrc", "libogg_hip.so")
 
 OGG_OK, OGG_EORDER, OGG_ESHAPE, OGG_EHIP, OGG_ENOMEM, OGG_EARG = 0, 1, 2, 3, 4, 5
 DP_ARC_LITERAL, DP_ARC_CHORD = 0, 1   # OGG_DP_ARC_* of include/ogg_hip.h

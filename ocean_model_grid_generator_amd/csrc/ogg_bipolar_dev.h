@@ -91,44 +91,44 @@ OGG_DEV void bp_point(const BpRow& r, const BpCol& c, double rp, double& phis, d
 // reference means reproducing that: every point carries a guard (below) and the cells with a guarded point are
 // re-evaluated with bp_point by a fix-up kernel (about 0.4 % of the cells at 1/8 degree, around the two pole points).
 //
-// Factored once more for the instruction count: with rden = 1/P, E = 1/D, Qs = E^2 rden, S = (1-A)(1+A) rden,
-//   h_j^2 N^2 = 4 rp^2 Qs X,  X = S a(1-a) b(1+b) + (1-a)          (OGG:81-88)
-//   h_i^2     = 4 rp^2 Qs Y,  Y = S (1+b) + a b                    (OGG:89-95)
-// and the callers fold 4 rp^2 into their per-row scale factors.
+// Cleared of its quotients for the instruction count: with P = 1 + a b = 1/rden and q = P D,
+//   h_j^2 N^2 = 4 rp^2 Xn / q^2,  Xn = (1-A^2) a(1-a) b(1+b) + (1-a) P = (1-a) + a(1-a) (b + (1-A^2) b(1+b))      (OGG:81-88)
+//   h_i^2     = 4 rp^2 Yn / q^2,  Yn = (1-A^2) (1+b) + a b P                                                      (OGG:89-95)
+//   D = (1 + rp^2) + (1 - rp^2) A
+// so dx = 2 rp sqrt(Yn) / q = 2 rp Yn / sqrt(Yn q^2), dy likewise from Xn, and a point that only feeds the area sum --
+// dx dy = 4 rp^2 sqrt(Xn Yn) / q^2 = 4 rp^2 Xn Yn / sqrt(Xn Yn q^4) -- costs ONE reciprocal square root and no reciprocal (Xn Yn q^4
+// <= (1+b)^8-ish: in range for b < 1e38, and the exact j = ny row, b = inf, never takes this path).  The callers fold 4 rp^2 into
+// their per-row scale factors.
 template <bool GUARD>
-OGG_DEV bool bp_point_fast(const BpRow& r, double b1, double bb1, const BpCol& c, double a1, double aa1, double rp2x4, double rp2,
-                           double guard_k, double& Qs, double& X, double& Y) {
-    // b1 = 1+b and bb1 = b (1+b) are row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them
-    const double a = c.alpha2, b = r.beta2_inv;
-    const double ab = a * b;
+OGG_DEV bool bp_point_fast(const BpRow& r, double b1, double bb1, const BpCol& c, double a1, double aa1, double rp2p, double rp2m,
+                           double guard_kk, double& q, double& Xn, double& Yn) {
+    // b1 = 1+b and bb1 = b (1+b) are row-only, a1 = 1-a and aa1 = a (1-a) are column-only: the callers hoist them;
+    // rp2p = 1 + rp^2, rp2m = 1 - rp^2
+    const double ab = c.alpha2 * r.beta2_inv;
     const double A = c.sinla * r.sphig;
-    const double p1 = 1 + A, m1 = 1 - A;
     const double P = 1.0 + ab;                    // 1/rden
-    const double D = fma(rp2, m1, p1);
-    const double inv = rcp_nr(P * D);             // one reciprocal for both quotients
-    const double rden = D * inv, E = P * inv;
-    const double EE = E * E;
-    const double mp = m1 * p1;
-    const double S = mp * rden;
-    const double uj = S * (aa1 * bb1), ui = S * b1;   // the cos^2(phis) terms of h_j^2, h_i^2 (up to the common factor)
-    Qs = EE * rden;
-    X = uj + a1;
-    Y = ui + ab;
+    const double D = fma(rp2m, A, rp2p);
+    const double mp = fma(-A, A, 1.0);            // (1-A)(1+A), one rounding
+    q = P * D;
+    Xn = fma(aa1, fma(mp, bb1, r.beta2_inv), a1);
+    Yn = fma(ab, P, mp * b1);
     // (the |beta2_inv| > HUGE case of OGG:86,94 only occurs on the exact j = ny row, which never takes this path)
     //
     // Exactness guard.  The literal sequence rounds phis = 90 - 2 atan(rp t)/PI_180 to a multiple of ulp(90) before taking
     // its cosine, which perturbs cos^2(phis) by up to 2.4e-16 / atan(rp t) relative; the algebraic value does not have that
     // perturbation, so where the cos^2 term carries weight w in h^2 the two differ by ~ w * 1.2e-16 / atan(rp t) in h.
-    // With atan(u) >= u/(1+u^2) = sqrt(cc)/2 the point is handed to the literal fix-up when w^2 > K * cc, i.e. when the
-    // difference could exceed ~ 2.4e-16 / sqrt(K) * ...  Measured against the oracle on the top 100 cell rows of the 1/8 degree cap
+    // With atan(u) >= u/(1+u^2) = sqrt(cc)/2 the point is handed to the literal fix-up when w^2 > K * cc, cc = cos^2(phis) =
+    // 4 rp^2 (1-A)(1+A) / D^2, i.e. when (ui D)^2 > K 4 rp^2 (1-A)(1+A) Yn^2 (or the same with uj, Xn).  Measured against the oracle
+    // on the top 100 cell rows of the 1/8 degree cap
     // (scripts/guard_k_probe.py), worst relative difference of dx / dy / area: every cell literal 5.8e-15 / 4.3e-15 / 3.5e-15
     // (ocml vs the host libm), K = 1000 5.8 / 6.1 / 5.0e-15, K = 4000 (default) 8.4 / 7.7 / 8.9e-15 with a quarter of the fix-up
     // cells, K = 16000 1.5e-14, no guard at all 6.8e-14 / 1.4e-13 / 6.9e-14 (area still within 3.3e-7 m^2).
     // Since w <= 1 a point can only be guarded where cos^2(phis) < 1/K, i.e. (phis <= grid latitude of the row) on the
     // lattice rows with cos^2(lat) < 1/K: the rows below that latitude run the GUARD = false instantiation.
     if (!GUARD) return false;
-    const double kc = guard_k * (rp2x4 * (EE * mp));   // K cos^2(phis)
-    return (ui * ui > kc * (Y * Y)) || (uj * uj > kc * (X * X));
+    const double kc = guard_kk * mp;                    // K 4 rp^2 (1-A)(1+A)
+    const double uid = (mp * b1) * D, ujd = (mp * (aa1 * bb1)) * D;   // the cos^2(phis) terms of h_i^2, h_j^2 (up to the common factor), times D
+    return (uid * uid > kc * (Yn * Yn)) || (ujd * ujd > kc * (Xn * Xn));
 }
 
 // lams of OGG:50-64
@@ -190,7 +190,7 @@ OGG_DEV double atan2_angle(double y, double x) {
     const double mx = fmax(ax, ay), mn = fmin(ax, ay);
     const bool big = mn > 0.41421356237309503 * mx;
     const double num = big ? mn - mx : mn, den = big ? mn + mx : mx;
-    const double r = num * rcp_nr(den);
+    const double r = num * rcp_c3(den);
     const double z = r * r;
     double p = 1.0 / 35.0;
     p = fma(p, z, -1.0 / 33.0), p = fma(p, z, 1.0 / 31.0), p = fma(p, z, -1.0 / 29.0), p = fma(p, z, 1.0 / 27.0);
@@ -259,7 +259,7 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
         const double lam = bp_lams(row, c, rden, lamg, lon_bp);
         const double A = c.sinla * row.sphig;
         const double m1 = 1 - A, p1 = 1 + A;
-        const double t = (m1 > 0.0) ? m1 * rsqrt_nr(m1 * p1) : 0.0;                    // sqrt((1-A)/(1+A)) == tan(acos(A)/2), OGG:69-70
+        const double t = (m1 > 0.0) ? m1 * rsqrt_c3(m1 * p1) : 0.0;                    // sqrt((1-A)/(1+A)) == tan(acos(A)/2), OGG:69-70
         const double u = rp * t;
         const double phi = 90 - div_pi180(2 * atan_cap(u));
         if (out) {
@@ -439,23 +439,26 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
         const double b1 = 1 + r.beta2_inv, bb1 = r.beta2_inv * b1, nsy = r.N_inv * sy;
         // 4 rp^2 folded into the scale factors of OGG:131-132: sqrt(4 rp^2) = 2 rp
         const double cdx = (2 * p.rp) * sx, cdy = (2 * p.rp) * nsy, cpr = rp2x4 * (sx * nsy);
+        const double guard_kk = p.guard_k * rp2x4, rp2p = 1 + rp2, rp2m = 1 - rp2;
         int g_first = 0, g_any = 0;
 #pragma unroll
         for (int ii = 0; ii < M; ++ii) {
-            double Qs, X, Y;
+            double q, Xn, Yn;
             const double a1 = 1 - col[ii].alpha2;
-            const bool g = bp_point_fast<MODE == QM_GUARD>(r, b1, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2x4, rp2, p.guard_k, Qs, X, Y);
+            const bool g = bp_point_fast<MODE == QM_GUARD>(r, b1, bb1, col[ii], a1, col[ii].alpha2 * a1, rp2p, rp2m, guard_kk, q, Xn, Yn);
             if (ii == 0) g_first = g;
             g_any |= (int)g;
-            // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): sqrt_nr(0) would be 0 * inf
+            const double q2 = q * q;
+            // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): Xn rsqrt(Xn ..) would be 0 * inf
             if (ii == 0 || want_dx) {
-                const double dx = sqrt_nr(Qs * Y) * cdx;
-                const double dy = (X > 0.0) ? sqrt_nr(Qs * X) * cdy : 0.0;
+                const double dx = (Yn * rsqrt_c3(Yn * q2)) * cdx;
+                const double dy = (Xn > 0.0) ? (Xn * rsqrt_c3(Xn * q2)) * cdy : 0.0;
                 o.dx[ii] = dx;
                 o.pr[ii] = dx * dy;
                 if (ii == 0) o.dy0 = dy;
             } else {
-                o.pr[ii] = (X > 0.0) ? (sqrt_nr(X * Y) * Qs) * cpr : 0.0;
+                const double xy = Xn * Yn;
+                o.pr[ii] = (Xn > 0.0) ? (xy * rsqrt_c3(xy * (q2 * q2))) * cpr : 0.0;
             }
         }
         o.guarded = 0;
