@@ -323,6 +323,10 @@ struct QuadParams {
     double* dyq;
     double* daq;
     QuadNodes q;
+    // constants of the algebraic per-point form, filled by plan_quad on the host (IEEE double, the operations a kernel would do) so
+    // that they sit in scalar registers: sx = 2 pi / nx, sy = (90 - lat0) PI_180 / ny (OGG:131-132), 1 +- rp^2, 4 rp^2, 2 rp sx,
+    // K 4 rp^2
+    double sx, sy, rp2p, rp2m, rp2x4, cdx, guard_kk;
 };
 
 struct QuadRange {     // the part of the band one grid of strip workgroups evaluates
@@ -407,8 +411,7 @@ struct RowEval {
 constexpr int QM_FAST = 0, QM_GUARD = 1, QM_LITERAL = 2;  // per-point method of the strip kernel
 
 template <int N, int MODE>
-OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* col, double sx, double sy, double rp2x4, double rp2,
-                              bool want_dx, RowEval<N, MODE>& o) {  // r: factors of the lattice row; r, want_dx wave-uniform
+OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* col, bool want_dx, RowEval<N, MODE>& o) {  // r: factors of the lattice row; r, want_dx wave-uniform
     // want_dx: the row is the bottom edge of a cell row, whose dx feeds dxq (OGG:183).  On the other rows the algebraic path
     // needs dx only inside the product dx*dy, which it then takes as sqrt(hi2*hj2) -- one square root instead of two.
     constexpr int M = N - 1;
@@ -436,10 +439,10 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
             if (ii == 0) o.dy0 = dy;
         }
     } else {
-        const double b1 = 1 + r.beta2_inv, bb1 = r.beta2_inv * b1, nsy = r.N_inv * sy;
+        const double b1 = 1 + r.beta2_inv, bb1 = r.beta2_inv * b1, nsy = r.N_inv * p.sy;
         // 4 rp^2 folded into the scale factors of OGG:131-132: sqrt(4 rp^2) = 2 rp
-        const double cdx = (2 * p.rp) * sx, cdy = (2 * p.rp) * nsy, cpr = rp2x4 * (sx * nsy);
-        const double guard_kk = p.guard_k * rp2x4, rp2p = 1 + rp2, rp2m = 1 - rp2;
+        const double cdx = p.cdx, cdy = (2 * p.rp) * nsy, cpr = p.rp2x4 * (p.sx * nsy);
+        const double guard_kk = p.guard_kk, rp2p = p.rp2p, rp2m = p.rp2m;
         int g_first = 0, g_any = 0;
 #pragma unroll
         for (int ii = 0; ii < M; ++ii) {
@@ -484,18 +487,16 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         if (u > n_cols_tab - 1) u = n_cols_tab - 1;
         col[ii] = p.col_tab[u];
     }
-    const double rp2 = p.rp * p.rp, rp2x4 = 4 * rp2;
-    const double sx = (2 * kPi) / (double)p.nx, sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
     const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
     RowEval<N, MODE> cur;
     if (rg.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
-        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, sx, sy, rp2x4, rp2, true, cur);
+        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, true, cur);
         if (cell_lane) p.dxq[rg.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
         return;
     }
     const long r0 = rg.row_begin + by * rg.rows_per_chunk;
     const long r1 = (r0 + rg.rows_per_chunk < rg.row_end) ? r0 + rg.rows_per_chunk : rg.row_end;
-    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, sx, sy, rp2x4, rp2, true, cur);
+    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, true, cur);
     for (long c = r0; c < r1; ++c) {
         const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
         int guarded = cur.guarded;                                          // bottom-edge row (carried)
@@ -508,7 +509,7 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         for (int jj = 0; jj < N; ++jj) {
             if (jj > 0) {
                 // the top row of this cell row is the bottom row of the next one (not needed past the end of the chunk)
-                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, sx, sy, rp2x4, rp2, jj == M && c + 1 < r1, cur);
+                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, jj == M && c + 1 < r1, cur);
                 guarded |= cur.guarded;
             }
             const double wj = quad_weight_1d<N>(jj);
@@ -704,6 +705,11 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     p.fix_count = fix_count;
     p.fix_list = fix_count + 4;
     p.guard_k = guard_k;
+    const double rp2 = p.rp * p.rp;
+    p.sx = (2 * kPi) / (double)p.nx, p.sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
+    p.rp2p = 1 + rp2, p.rp2m = 1 - rp2, p.rp2x4 = 4 * rp2;
+    p.cdx = (2 * p.rp) * p.sx;
+    p.guard_kk = guard_k * p.rp2x4;
     out.p = p;
     const long n_strips = (p.nx + QS_CELLS - 1) / QS_CELLS;
     out.gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
         const long t = take_ticket(a.dm.ticket, &s_slot);
         dpole_mesh_body(a.dm, lds.dmesh, t % a.dm.gx, t / a.dm.gx);
     } else if (role == ROLE_BP_GUARD) {
+        asm volatile("; role: guarded quadrature strips" ::: "memory");
         bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
     } else if (role == ROLE_BP_FAST) {
+        asm volatile("; role: quadrature strips" ::: "memory");
         bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
     } else if (role == ROLE_DP_QUAD) {
         const long strip = (b % a.dq.gx) * DQ_WAVES + (threadIdx.x >> 6), chunk = b / a.dq.gx;

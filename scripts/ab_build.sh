@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build the library of another git revision into ab/libogg_hip_<name>.so (in-tree, so that it travels to the GPU box; *.so is
+# git-ignored), for A/B timing of two builds on ONE box:   scripts/ab_build.sh <rev> <name>
+#   then on the GPU box:   python scripts/ab_time.py --libs ab/libogg_hip_<name>.so ocean_model_grid_generator_amd/csrc/libogg_hip.so
+set -e
+rev=$1; name=$2
+root=$(cd "$(dirname "$0")/.." && pwd)
+tmp=$(mktemp -d)
+mkdir -p "$tmp/ocean_model_grid_generator_amd" "$root/ab"
+git -C "$root" archive "$rev" ocean_model_grid_generator_amd/csrc include | tar -x -C "$tmp"
+cd "$tmp/ocean_model_grid_generator_amd/csrc"
+for f in *.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -w -c $f -o ${f%.hip}.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC *.o -o "$root/ab/libogg_hip_$name.so"
+rm -rf "$tmp"
+ls -la "$root/ab/libogg_hip_$name.so"
