@@ -153,6 +153,78 @@ def _dp_parity(arc):
             "chord_vs_literal_max_rel": rec["full_size_chord_vs_literal_max_rel"]}
 
 
+def power_probe(sg, torch, seconds, card_index=0):
+    """Socket power and clocks (rocm-smi) while (a) the fused pass, (b) the stand-alone lat-lon kernel, (c) the stand-alone cap kernels run
+    in a loop for `seconds` each, after the timed region.  The fused pass of the headline workload draws the socket's power limit
+    (1.4 kW) and the shader clock drops ~13 % below what either kernel class holds alone: the third roofline."""
+    import subprocess
+    import threading
+
+    def smi():
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
+            d = json.loads(out)
+            cards = sorted(k for k in d if k.startswith("card"))
+            c = d["card%d" % card_index] if ("card%d" % card_index) in d else d[cards[0]]
+            num = lambda v: float(str(v).strip("()").lower().replace("mhz", ""))
+            return {"watts": num(next(v for k, v in c.items() if "power" in k.lower())),
+                    "sclk_mhz": num(next(v for k, v in c.items() if k.lower().startswith("sclk clock speed"))),
+                    "mclk_mhz": num(next(v for k, v in c.items() if k.lower().startswith("mclk clock speed"))),
+                    "junction_c": num(next(v for k, v in c.items() if "junction" in k.lower()))}
+        except Exception:  # noqa: BLE001 -- no rocm-smi, no permission, another JSON layout: no probe
+            return None
+
+    if smi() is None:
+        return None
+    caps = [x.name for x in sg.plan.subs if x.kind in ("bipolar", "dpole")]
+    saved = (sg.launch, sg.overlap, sg._events)
+    sg._events = None
+
+    def latlon_alone():
+        sg.phase_a(kinds=("mercator", "latlon"))
+        sg.phase_b(kinds=("mercator", "latlon"))
+
+    def caps_alone():
+        for c in caps:
+            sg.phase_a(only=c)
+            sg.phase_b(only=c)
+
+    out = {}
+    for name, launch, fn in (("fused_pass", "pass", sg.run_pass), ("latlon_kernel_alone", "kernels", latlon_alone),
+                             ("cap_kernels_alone", "kernels", caps_alone)):
+        if name == "cap_kernels_alone" and not caps:
+            continue
+        sg.launch, sg.overlap = launch, False
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                v = smi()
+                if v:
+                    samples.append(v)
+                stop.wait(0.3)
+
+        th = threading.Thread(target=sampler)
+        th.start()
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            n += 50
+        dt = time.perf_counter() - t0
+        stop.set()
+        th.join()
+        use = samples[1:] if len(samples) > 2 else samples     # the first sample may precede the ramp
+        if use:
+            out[name] = {k: round(sum(v[k] for v in use) / len(use), 1) for k in use[0]}
+            out[name].update({"samples": len(use), "ms_per_call": round(dt / n * 1e3, 5),
+                              "joules_per_call": round(out[name]["watts"] * dt / n, 5)})
+    sg.launch, sg.overlap, sg._events = saved
+    return out or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +244,8 @@ def main():
     ap.add_argument("--checksum", type=int, default=1, help="after the timed region: 64-bit sums of the bit patterns of every field of every "
                     "sub-grid, added over the ranks (one all-reduce): a band-sharded run must print the single-GPU values")
     ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
+    ap.add_argument("--power-probe", type=float, default=1.5, help="after the timed region (1 GPU): seconds per phase of the rocm-smi power / "
+                    "clock probe (fused pass, lat-lon kernel alone, cap kernels alone); 0: skip")
     ap.add_argument("--dp-arc", default="chord", choices=["chord", "literal"],
                     help="arc form of the displaced-pole quadrature (workloads with a displaced pole only): chord (same finite-difference "
                          "stencil, distances from the probes' positions on the sphere) or literal (the reference's haversine arithmetic); "
@@ -333,6 +407,12 @@ def main():
             del pinned
         except Exception as exc:
             d2h = {"error": repr(exc)}
+    power = None
+    if args.power_probe > 0 and world == 1 and args.latlon == "fused" and args.as_rank is None:
+        try:
+            power = power_probe(sg, torch, args.power_probe, local_rank)
+        except Exception as exc:  # never lose the bench line over the probe
+            power = {"error": repr(exc)}
     # per-kernel durations: the same K passes again, launched eagerly with HIP events around every kernel on the launch
     # stream (events cannot be read back from inside a replayed graph)
     timed_launch = "%s%s%s" % (sg.launch, ", caps on side streams" if (sg.launch == "kernels" and sg.overlap) else "",
@@ -422,7 +502,15 @@ def main():
             "self_check_metrics_error_percent": self_check, "field_checksums": checksums,
             "d2h_pinned_after_pass": d2h,
             "kernels": kernels,
+            "power": power,
         }
+        fp = (power or {}).get("fused_pass")
+        if fp and "watts" in fp:
+            alone = [v["sclk_mhz"] for k, v in power.items() if k != "fused_pass" and isinstance(v, dict) and "sclk_mhz" in v]
+            if alone and fp["sclk_mhz"] < 0.95 * min(alone):
+                roof["limited_by"] = ("%s; DVFS: the fused pass holds %.0f MHz at %.0f W socket power where either kernel class alone holds "
+                                      ">= %.0f MHz (`power`, rocm-smi samples after the timed region)"
+                                      % (roof.get("limited_by") or "instruction count", fp["sclk_mhz"], fp["watts"], min(alone)))
         if world == 1 and args.cpu_sample_div > 0:
             cells, cdt = cpu_baseline(flags, args.cpu_sample_div)
             out["cpu_baseline"] = {"value": cells / cdt, "unit": "cells/s", "cores": 1, "kind": "port",

@@ -166,19 +166,24 @@ __global__ void bipolar_projection_kernel(long n, const double* __restrict__ lam
 // ocml's atan and atan2 spend two thirds of their instructions on what this kernel never feeds them (infinities, NaNs, signed zeros,
 // |x| > 1, range selection): 83 and 114 instructions for 35 and 44 of fp64 arithmetic.
 //
+// Series coefficients through scalar registers (ogg_math.h, horner_scalar): a Horner step is one vector instruction, not three.
+__constant__ double kAtanOdd[18] = {1.0 / 3.0,  -1.0 / 5.0,  1.0 / 7.0,  -1.0 / 9.0,  1.0 / 11.0, -1.0 / 13.0, 1.0 / 15.0, -1.0 / 17.0, 1.0 / 19.0,
+                                    -1.0 / 21.0, 1.0 / 23.0, -1.0 / 25.0, 1.0 / 27.0, -1.0 / 29.0, 1.0 / 31.0, -1.0 / 33.0, 1.0 / 35.0, 0.0};
+
+// r - r^3 (1/3 - r^2/5 + ...): the odd Taylor series of atan with TERMS coefficients
+template <int TERMS>
+OGG_DEV double atan_series(double r) {
+    const double z = r * r;
+    return fma(-(r * z), horner_scalar<TERMS>(kAtanOdd, z), r);
+}
+
 // atan(u) for 0 <= u <= 0.3 -- u = rp tan(chi/2) <= rp = tan(13 degrees) = 0.23 for every cap main() builds -- from 14 terms of the odd
 // Taylor series in Horner form (the first omitted term is below 5e-18 relative): 0.57 ulp at worst (validated on the host against
-// atanl on 3e7 arguments; glibc: 0.52), 19 instructions.  A wave with any larger argument (a cap that starts south of 56.6 degrees)
-// takes ocml's atan, behind one ballot.
+// atanl on 3e7 arguments; glibc: 0.52).  A wave with any larger argument (a cap that starts south of 56.6 degrees) takes ocml's atan,
+// behind one ballot.
 OGG_DEV double atan_cap(double u) {
     if (__builtin_expect(__ballot(!(u <= 0.3)) != 0ull, 0)) return atan(u);
-    const double z = u * u;
-    double p = -1.0 / 29.0;
-    p = fma(p, z, 1.0 / 27.0), p = fma(p, z, -1.0 / 25.0), p = fma(p, z, 1.0 / 23.0), p = fma(p, z, -1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0), p = fma(p, z, -1.0 / 17.0), p = fma(p, z, 1.0 / 15.0), p = fma(p, z, -1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0), p = fma(p, z, -1.0 / 9.0), p = fma(p, z, 1.0 / 7.0), p = fma(p, z, -1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    return fma(-(u * z), p, u);
+    return atan_series<14>(u);
 }
 
 // atan2(y, x) for the fused angle_x (finite arguments): octant reduction with ONE reciprocal -- r = (mn - mx) / (mn + mx) when
@@ -190,14 +195,7 @@ OGG_DEV double atan2_angle(double y, double x) {
     const double mx = fmax(ax, ay), mn = fmin(ax, ay);
     const bool big = mn > 0.41421356237309503 * mx;
     const double num = big ? mn - mx : mn, den = big ? mn + mx : mx;
-    const double r = num * rcp_c3(den);
-    const double z = r * r;
-    double p = 1.0 / 35.0;
-    p = fma(p, z, -1.0 / 33.0), p = fma(p, z, 1.0 / 31.0), p = fma(p, z, -1.0 / 29.0), p = fma(p, z, 1.0 / 27.0);
-    p = fma(p, z, -1.0 / 25.0), p = fma(p, z, 1.0 / 23.0), p = fma(p, z, -1.0 / 21.0), p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, -1.0 / 17.0), p = fma(p, z, 1.0 / 15.0), p = fma(p, z, -1.0 / 13.0), p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, -1.0 / 9.0), p = fma(p, z, 1.0 / 7.0), p = fma(p, z, -1.0 / 5.0), p = fma(p, z, 1.0 / 3.0);
-    double a = fma(-(r * z), p, r);
+    double a = atan_series<17>(num * rcp_c3(den));
     a = big ? 0.78539816339744830962 + a : a;          // atan(mn / mx) in [0, pi/4]
     a = (ay > ax) ? 1.57079632679489661923 - a : a;
     a = (x < 0.0) ? 3.14159265358979323846 - a : a;
@@ -213,17 +211,18 @@ OGG_DEV double atan2_angle(double y, double x) {
 // the scale factors, when requested, follow the literal sequence (bp_point).
 constexpr int MESH_WAVES = 4;
 constexpr int MESH_OUT = 62;   // output columns per wave
-constexpr int MESH_ROWS = 8;   // rows per workgroup (OGG_MESH_ROWS: fewer, for experiments)
+constexpr int MESH_ROWS = 8;       // rows per workgroup: the default (OGG_MESH_ROWS: 1 .. MESH_ROWS_MAX)
+constexpr int MESH_ROWS_MAX = 32;  // LDS entries for the row factors
 
 struct MeshParams {
     long Ni, Nj;
     double lat0_bp, lon_bp;
     long j0, nrows;
     double *lams, *phis, *hi, *hj, *angle;
-    int rows_per_wg;   // 1..MESH_ROWS
+    int rows_per_wg;   // 1..MESH_ROWS_MAX
 };
 
-// workgroup (bx, by) of the mesh grid; s_row: MESH_ROWS entries of LDS.  WITH_H = false leaves the scale factors out of the
+// workgroup (bx, by) of the mesh grid; s_row: MESH_ROWS_MAX entries of LDS.  WITH_H = false leaves the scale factors out of the
 // code (the pass never asks for them; with them the kernel needs 183 VGPRs = 2 waves per SIMD).
 template <bool WITH_H>
 OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long by) {
@@ -277,7 +276,7 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
             const double yl = wave_prev(phi), yr = wave_next(phi);
             // cos(phi PI/180) = sin(2 atan u) = 2u/(1+u^2): differs from the cosine of the ROUNDED phi by < 7e-15/(90-phi) relative,
             // three orders below what the last-ulp differences of lam, phi do to their finite differences here
-            const double cy = (2 * u) / (1 + u * u);
+            const double cy = (2 * u) * rcp_c3(1 + u * u);
             double a;
             if (i == 0)
                 a = atan2_angle(yr - phi, (xr - lam) * cy);
@@ -292,7 +291,7 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
 
 template <bool WITH_H>
 __global__ __launch_bounds__(64 * MESH_WAVES) void bipolar_mesh_kernel(MeshParams m) {
-    __shared__ BpRow s_row[MESH_ROWS];
+    __shared__ BpRow s_row[MESH_ROWS_MAX];
     bipolar_mesh_body<WITH_H>(m, s_row, blockIdx.x, blockIdx.y);
 }
 
@@ -302,7 +301,7 @@ inline dim3 mesh_grid(MeshParams& m) {
     const long n_waves = (m.Ni + 1 + MESH_OUT - 1) / MESH_OUT;
     const long gx = (n_waves + MESH_WAVES - 1) / MESH_WAVES;
     long rpw = MESH_ROWS;
-    if (const char* e = getenv("OGG_MESH_ROWS")) rpw = atol(e) < 1 ? 1 : (atol(e) > MESH_ROWS ? MESH_ROWS : atol(e));
+    if (const char* e = getenv("OGG_MESH_ROWS")) rpw = atol(e) < 1 ? 1 : (atol(e) > MESH_ROWS_MAX ? MESH_ROWS_MAX : atol(e));
     m.rows_per_wg = (int)rpw;
     return dim3((unsigned)gx, (unsigned)((m.nrows + rpw - 1) / rpw));
 }
@@ -411,7 +410,7 @@ struct RowEval {
 constexpr int QM_FAST = 0, QM_GUARD = 1, QM_LITERAL = 2;  // per-point method of the strip kernel
 
 template <int N, int MODE>
-OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* col, bool want_dx, RowEval<N, MODE>& o) {  // r: factors of the lattice row; r, want_dx wave-uniform
+OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* col, double rp2p, bool want_dx, RowEval<N, MODE>& o) {  // r: factors of the lattice row; r, want_dx wave-uniform
     // want_dx: the row is the bottom edge of a cell row, whose dx feeds dxq (OGG:183).  On the other rows the algebraic path
     // needs dx only inside the product dx*dy, which it then takes as sqrt(hi2*hj2) -- one square root instead of two.
     constexpr int M = N - 1;
@@ -442,7 +441,7 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
         const double b1 = 1 + r.beta2_inv, bb1 = r.beta2_inv * b1, nsy = r.N_inv * p.sy;
         // 4 rp^2 folded into the scale factors of OGG:131-132: sqrt(4 rp^2) = 2 rp
         const double cdx = p.cdx, cdy = (2 * p.rp) * nsy, cpr = p.rp2x4 * (p.sx * nsy);
-        const double guard_kk = p.guard_kk, rp2p = p.rp2p, rp2m = p.rp2m;
+        const double guard_kk = p.guard_kk, rp2m = p.rp2m;   // rp2p: in a vector register (D = fma(rp2m, A, rp2p) may read ONE scalar operand)
         int g_first = 0, g_any = 0;
 #pragma unroll
         for (int ii = 0; ii < M; ++ii) {
@@ -452,16 +451,18 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
             if (ii == 0) g_first = g;
             g_any |= (int)g;
             const double q2 = q * q;
-            // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84): Xn rsqrt(Xn ..) would be 0 * inf
+            // h_j vanishes identically on the meridians alpha2 == 1 (OGG:81-84), where Xn == 0 exactly: the argument of the reciprocal
+            // square root is held above zero, so that Xn rsqrt(..) is 0 * finite = 0 there without a branch around the point
+            constexpr double tiny = 1e-290;
             if (ii == 0 || want_dx) {
                 const double dx = (Yn * rsqrt_c3(Yn * q2)) * cdx;
-                const double dy = (Xn > 0.0) ? (Xn * rsqrt_c3(Xn * q2)) * cdy : 0.0;
+                const double dy = (Xn * rsqrt_c3(fmax(Xn * q2, tiny))) * cdy;
                 o.dx[ii] = dx;
                 o.pr[ii] = dx * dy;
                 if (ii == 0) o.dy0 = dy;
             } else {
                 const double xy = Xn * Yn;
-                o.pr[ii] = (Xn > 0.0) ? (xy * rsqrt_c3(xy * (q2 * q2))) * cpr : 0.0;
+                o.pr[ii] = (xy * rsqrt_c3(fmax(xy * (q2 * q2), tiny))) * cpr;
             }
         }
         o.guarded = 0;
@@ -488,15 +489,17 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         col[ii] = p.col_tab[u];
     }
     const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
+    double rp2p = p.rp2p;
+    asm volatile("" : "+v"(rp2p));   // held in a vector register for the whole walk (else re-copied from its scalar register per point)
     RowEval<N, MODE> cur;
     if (rg.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
-        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, true, cur);
+        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, rp2p, true, cur);
         if (cell_lane) p.dxq[rg.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
         return;
     }
     const long r0 = rg.row_begin + by * rg.rows_per_chunk;
     const long r1 = (r0 + rg.rows_per_chunk < rg.row_end) ? r0 + rg.rows_per_chunk : rg.row_end;
-    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, true, cur);
+    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, rp2p, true, cur);
     for (long c = r0; c < r1; ++c) {
         const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
         int guarded = cur.guarded;                                          // bottom-edge row (carried)
@@ -509,7 +512,7 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         for (int jj = 0; jj < N; ++jj) {
             if (jj > 0) {
                 // the top row of this cell row is the bottom row of the next one (not needed past the end of the chunk)
-                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, jj == M && c + 1 < r1, cur);
+                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, rp2p, jj == M && c + 1 < r1, cur);
                 guarded |= cur.guarded;
             }
             const double wj = quad_weight_1d<N>(jj);

@@ -146,6 +146,36 @@ OGG_DEV double sqrt_c3(double x) {     // g = x y is sqrt(x) (1 - e)^(1/2) up to
     return fma(g * e, fma(e, 0.375, 0.5), g);
 }
 
+// Polynomial coefficients as SCALAR operands.  A 64-bit literal cannot be an operand of a gfx9 VALU instruction: the compiler
+// materialises each coefficient with two v_mov_b32 in front of its fma, so a Horner step costs three vector instructions instead of
+// one (ocml's own polynomials pay the same).  Kept in a __constant__ table the coefficients arrive by scalar loads (one
+// s_load_dwordx16 per 8) and feed v_fma_f64 as scalar operands.  Two details make the compiler do it:
+//   * the table pointer passes through an empty asm, or a table with internal linkage is folded back into literals;
+//   * every coefficient is "used" once more by an empty asm behind the chain: a scalar addend that dies at its fma is otherwise
+//     copied into vector registers for the two-address v_fmac_f64 form.
+typedef const double __attribute__((address_space(4))) * coef_table_t;
+
+OGG_DEV coef_table_t scalar_table(const double* t) {
+    coef_table_t p = (coef_table_t)t;
+    asm("" : "+s"(p));
+    return p;
+}
+
+// c[N-1] z^(N-1) + ... + c[1] z + c[0], Horner, coefficients from a __constant__ table through scalar registers
+template <int N>
+OGG_DEV double horner_scalar(const double* table, double z) {
+    const coef_table_t c = scalar_table(table);
+    double k[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) k[i] = c[i];
+    double p = k[N - 1];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) p = fma(p, z, k[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" ::"s"(k[i]));
+    return p;
+}
+
 // Neighbour lanes of a wave64 through DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130): two VALU moves per
 // double instead of two ds_bpermute round trips through the LDS crossbar.  The end lanes keep their own value, like
 // __shfl_up / __shfl_down with delta 1.

@@ -40,7 +40,7 @@ struct LatlonShare {
 
 union PassLds {
     RowScalars ll[LF_ROWS + 1];
-    BpRow mesh[MESH_ROWS];
+    BpRow mesh[MESH_ROWS_MAX];
     DpMeshLds dmesh;
 };
 
@@ -173,7 +173,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // measured optima (1/8 degree, shares 1, 1/2, 1/4, 1/8 = 19.8, 9.9, 5, 2.5 M points): 60, 90, 90-120, 120 -- the smaller the share,
     // the shorter the VALU work the strips can hide behind, so they need more of the write bandwidth
     long max_wg = alone ? 2048
-                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", 60)
+                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", 90)
                                               : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", 90) : env_long("OGG_PASS_LL_WG_SMALL", 120)));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;

@@ -143,7 +143,7 @@ class SupergridPlan(object):
             # Row cost for the band split of the cap, in units of a plain cell row.  The quadrature guards its algebraic per-point form
             # near the two pole points (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K))
             # carry the guard (1.3x a plain row), and the band that holds the last row also runs the tail launch (literal fix-up of the
-            # guarded cells + the j = ny row), a fixed cost worth ~30 plain rows whatever the resolution.  These weights equalise the
+            # guarded cells + the j = ny row), a fixed cost worth ~50 plain rows of the round-2 quadrature whatever the resolution.  These weights equalise the
             # measured per-rank times of the fused pass at 1/8 and 1/16 degree over 2, 4 and 8 ranks (scripts/rank_sweep.py;
             # OGG_BP_ROW_COST="fix,guard,lump" overrides them: weight of rows with fix-up cells, of guarded rows, lump on the last row).
             import os
@@ -152,7 +152,7 @@ class SupergridPlan(object):
                 lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
                 guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
                 fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
-                w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,30").split(",")]
+                w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,50").split(",")]
                 w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
                 bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
                 bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents

@@ -16,7 +16,7 @@ from ocean_model_grid_generator_amd import supergrid  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--workload", default="r8")
-ap.add_argument("--cost", nargs="*", default=["1.3,1.3,30"])
+ap.add_argument("--cost", nargs="*", default=["1.3,1.3,50"])
 ap.add_argument("--dp-arc", default="chord")
 ap.add_argument("--json", default=None, help="append one JSON line per (world, cost) to this file")
 ap.add_argument("--steps", type=int, default=200)
