@@ -82,16 +82,28 @@ OGG_DEV ColScalars column_scalars(const FusedParams& p, long i) {
 // instructions per row, not the store width.
 typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
 
-// FULL: both columns exist (one unconditional 16-byte store); else each one on its own flag
-template <bool FULL>
+// FULL: both columns exist (one unconditional 16-byte store); else each one on its own flag.
+// NT: non-temporal stores (`global_store_dwordx4 ... nt`).  Alone, the kernel is 5 % SLOWER with them (0.197-0.227 against 0.189-0.211 ms
+// on one box, whose write path slows down as it warms up); as a role of the fused pass, next to cap workgroups that keep the
+// socket at its power limit, the pass is 6-15 % FASTER with them and no longer follows that drift (0.249-0.256 against 0.264-0.299 ms,
+// scripts/ab_time.py on one box): the pass sets NT, the stand-alone launch does not.
+template <bool FULL, bool NT>
 OGG_DEV void store2(double* q, double a, double b, bool first, bool second) {
     if (FULL) {
         dbl2 v;
         v.x = a, v.y = b;
-        *reinterpret_cast<dbl2*>(q) = v;
+        if (NT)
+            __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(q));
+        else
+            *reinterpret_cast<dbl2*>(q) = v;
     } else {
-        if (first) q[0] = a;
-        if (second) q[1] = b;
+        if (NT) {
+            if (first) __builtin_nontemporal_store(a, q);
+            if (second) __builtin_nontemporal_store(b, q + 1);
+        } else {
+            if (first) q[0] = a;
+            if (second) q[1] = b;
+        }
     }
 }
 
@@ -105,7 +117,7 @@ OGG_DEV double latlon_angle(double pa) {
 // The rows js .. js+nrows-1 of one band for this thread's two columns.  FULL: both columns exist and both have a right
 // neighbour -- every thread but the last one or two of a row -- so the loop has no per-lane branch: what limits a lat-lon
 // workgroup is the instruction count per row, not the store width.
-template <bool FULL>
+template <bool FULL, bool NT>
 OGG_DEV void latlon_rows(const FusedParams& p, const ogg_latlon_band& b, const RowScalars* s_row, long js, int nrows, long n_cell_rows,
                          long i0, const ColScalars& c0, const ColScalars& c1) {
     const long ni1 = p.ni1, ni = ni1 - 1;
@@ -119,16 +131,16 @@ OGG_DEV void latlon_rows(const FusedParams& p, const ogg_latlon_band& b, const R
     for (int r = 0; r < nrows; ++r) {
         const long j = js + r;
         const RowScalars rs = s_row[r];
-        store2<FULL>(px, c0.lon_c, c1.lon_c, true, pt1);
-        store2<FULL>(py, rs.lat, rs.lat, true, pt1);
-        store2<FULL>(pa, latlon_angle(c0.xdiff * rs.cl), latlon_angle(c1.xdiff * rs.cl), true, pt1);
+        store2<FULL, NT>(px, c0.lon_c, c1.lon_c, true, pt1);
+        store2<FULL, NT>(py, rs.lat, rs.lat, true, pt1);
+        store2<FULL, NT>(pa, latlon_angle(c0.xdiff * rs.cl), latlon_angle(c1.xdiff * rs.cl), true, pt1);
         if (p.metrics) {
             // dx = Re sqrt(0 + t^2) with t = dlam cos(lv): sqrt(RN(t^2)) == |t| in binary floating point (no over/underflow here)
-            store2<FULL>(pdx, p.Re * fabs(c0.dlam * rs.cl), p.Re * fabs(c1.dlam * rs.cl), ce0, false);
+            store2<FULL, NT>(pdx, p.Re * fabs(c0.dlam * rs.cl), p.Re * fabs(c1.dlam * rs.cl), ce0, false);
             if (j < n_cell_rows) {
-                store2<FULL>(pdy, rs.dy, rs.dy, true, pt1);
+                store2<FULL, NT>(pdy, rs.dy, rs.dy, true, pt1);
                 const double ds = s_row[r + 1].sl - rs.sl;
-                store2<FULL>(par, p.Re2 * (c0.hdlam * ds), p.Re2 * (c1.hdlam * ds), ce0, false);
+                store2<FULL, NT>(par, p.Re2 * (c0.hdlam * ds), p.Re2 * (c1.hdlam * ds), ce0, false);
             }
         }
         px += ni1, py += ni1, pa += ni1, pdy += ni1;
@@ -144,6 +156,7 @@ inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
 // the 8 XCDs round-robin, so workgroup b runs on XCD b % 8; the remap below gives every XCD a CONTIGUOUS eighth of the row
 // strips (all column tiles of those rows) and every workgroup a contiguous block of strips, instead of interleaving the XCDs
 // strip by strip: +15 % on the write plateau in scripts/microbench/write_patterns.hip (pattern b2).
+template <bool NT>
 OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi) {
     const long v = xcd_contiguous(b, gx * gy);   // virtual index: the workgroups of XCD x are consecutive
     const long bx = v % gx, by = v / gx;
@@ -186,16 +199,16 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
         }
         __syncthreads();
         if (full)
-            latlon_rows<true>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
+            latlon_rows<true, NT>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
         else if (i0 < ni1)  // the last column (ni1 odd) or the last pair (no dx / area in its second column)
-            latlon_rows<false>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
+            latlon_rows<false, NT>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
         __syncthreads();  // the row table is rewritten by the next strip
     }
 }
 
 __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
     __shared__ RowScalars s_row[LF_ROWS + 1];
-    latlon_fused_body(p, s_row, (long)blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, 0, p.strip0[p.n_bands]);
+    latlon_fused_body<false>(p, s_row, (long)blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, 0, p.strip0[p.n_bands]);
 }
 
 // Validates the bands and fills the kernel parameters; returns the number of points (0: nothing to do).

@@ -28,6 +28,7 @@
 namespace {
 
 constexpr int PASS_TX = 256;
+constexpr bool PASS_LL_NT = true;   // the lat-lon strips of a pass store non-temporally (ogg_latlon_fused_dev.h, store2)
 static_assert(PASS_TX == LF_TX && PASS_TX == 64 * MESH_WAVES && PASS_TX == 64 * QS_WAVES && PASS_TX == 64 * DM_WAVES &&
                   PASS_TX == 64 * DQ_WAVES,
               "one workgroup shape for all roles");
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
     __shared__ PassLds lds;
     long b = blockIdx.x;
     if (b < a.share.n_wg) {
-        latlon_fused_body(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        latlon_fused_body<PASS_LL_NT>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
         return;
     }
     b -= a.share.n_wg;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ unsigned s_slot;
     long b = blockIdx.x;
     if (b < a.share.n_wg) {
-        latlon_fused_body(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        latlon_fused_body<PASS_LL_NT>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
         return;
     }
     b -= a.share.n_wg;
