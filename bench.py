@@ -463,8 +463,8 @@ def main():
                     "limited_by": "fp64 VALU issue, not HBM (see roofline_valu)" if (vc and vc["valu_busy_frac"] > 0.6) else None,
                     "note": "longest of the launches of the fused pass; HIP events recorded by the library on the launch stream in "
                             "%d passes of the timed region.  It carries lat-lon row strips (HBM-write bound) AND cap mesh / quadrature "
-                            "workgroups (fp64-VALU bound, DESIGN.md 4): its duration is set by the VALU work, its bytes mostly by the "
-                            "lat-lon strips, so `frac` is what the WORKLOAD allows, not a statement about the write path.  `kernels` lists the "
+                            "workgroups (fp64-VALU bound, DESIGN.md 4); with both active the socket sits at its power limit and the clock "
+                            "drops (`power`), so `frac` is what the WORKLOAD allows, not a statement about the write path.  `kernels` lists the "
                             "stand-alone kernels, one after the other." % n_sampled}
             if vc:
                 # issue-time floor of the launch: every wave64 VALU instruction occupies its SIMD for >= 4 cycles (quarter-rate fp64
@@ -508,9 +508,10 @@ def main():
         if fp and "watts" in fp:
             alone = [v["sclk_mhz"] for k, v in power.items() if k != "fused_pass" and isinstance(v, dict) and "sclk_mhz" in v]
             if alone and fp["sclk_mhz"] < 0.95 * min(alone):
-                roof["limited_by"] = ("%s; DVFS: the fused pass holds %.0f MHz at %.0f W socket power where either kernel class alone holds "
-                                      ">= %.0f MHz (`power`, rocm-smi samples after the timed region)"
-                                      % (roof.get("limited_by") or "instruction count", fp["sclk_mhz"], fp["watts"], min(alone)))
+                roof["limited_by"] = ("socket power: the fused pass holds %.0f MHz at %.0f W where either kernel class alone holds >= %.0f MHz "
+                                      "(`power`: rocm-smi samples after the timed region; DVFS give-back, DESIGN.md 4)%s"
+                                      % (fp["sclk_mhz"], fp["watts"], min(alone),
+                                         ("; below that, " + roof["limited_by"]) if roof.get("limited_by") else ""))
         if world == 1 and args.cpu_sample_div > 0:
             cells, cdt = cpu_baseline(flags, args.cpu_sample_div)
             out["cpu_baseline"] = {"value": cells / cdt, "unit": "cells/s", "cores": 1, "kind": "port",

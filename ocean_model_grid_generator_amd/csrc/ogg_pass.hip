@@ -28,7 +28,6 @@
 namespace {
 
 constexpr int PASS_TX = 256;
-constexpr bool PASS_LL_NT = true;   // the lat-lon strips of a pass store non-temporally (ogg_latlon_fused_dev.h, store2)
 static_assert(PASS_TX == LF_TX && PASS_TX == 64 * MESH_WAVES && PASS_TX == 64 * QS_WAVES && PASS_TX == 64 * DM_WAVES &&
                   PASS_TX == 64 * DQ_WAVES,
               "one workgroup shape for all roles");
@@ -37,6 +36,7 @@ struct LatlonShare {
     long n_wg;      // workgroups of this launch that stream lat-lon strips (gx * gy)
     long gx, gy;
     long strip_lo, strip_hi;
+    int nt;         // non-temporal stores (ogg_latlon_fused_dev.h, store2): when the strips share the launch with cap workgroups
 };
 
 union PassLds {
@@ -64,7 +64,10 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
     __shared__ PassLds lds;
     long b = blockIdx.x;
     if (b < a.share.n_wg) {
-        latlon_fused_body<PASS_LL_NT>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        if (a.share.nt)
+            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        else
+            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
         return;
     }
     b -= a.share.n_wg;
@@ -114,7 +117,10 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ unsigned s_slot;
     long b = blockIdx.x;
     if (b < a.share.n_wg) {
-        latlon_fused_body<PASS_LL_NT>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        if (a.share.nt)
+            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+        else
+            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
         return;
     }
     b -= a.share.n_wg;
@@ -167,6 +173,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     LatlonShare s{};
     s.gx = latlon_gx(ni1);
     s.strip_lo = lo, s.strip_hi = hi;
+    s.nt = alone ? 0 : (int)env_long("OGG_PASS_LL_NT", 1);
     if (hi <= lo) return s;
     // resident lat-lon workgroups: enough to keep the HBM write path busy and not more, so that the VALU-bound workgroups of
     // the same launch get the remaining wave slots; a launch without compute workgroups takes the whole chip

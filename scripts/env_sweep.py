@@ -1,0 +1,44 @@
+"""Time the fused pass of one workload under several settings of ONE environment knob, in one process on one box.
+
+usage: python scripts/env_sweep.py --workload r16 --var OGG_PASS_LL_NT --values 0 1 0 1 [--steps 100] [--set K=V ...]
+(The library reads its tuning knobs from the environment at every call.)
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from ocean_model_grid_generator_amd import supergrid  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="r8")
+ap.add_argument("--var", required=True)
+ap.add_argument("--values", nargs="+", required=True)
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--set", nargs="*", default=[])
+ap.add_argument("--as-rank", type=int, default=0)
+ap.add_argument("--as-world", type=int, default=1)
+args = ap.parse_args()
+for kv in args.set:
+    k, v = kv.split("=", 1)
+    os.environ[k] = v
+plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
+sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device="cuda:0", halo="recompute")
+sg.launch = "pass"
+for _ in range(60):
+    sg.run_pass()
+torch.cuda.synchronize()
+for v in args.values:
+    os.environ[args.var] = v
+    for _ in range(10):
+        sg.run_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sg.run_pass()
+    torch.cuda.synchronize()
+    print("%s %s=%s: %.4f ms" % (args.workload, args.var, v, (time.perf_counter() - t0) / args.steps * 1e3), flush=True)
