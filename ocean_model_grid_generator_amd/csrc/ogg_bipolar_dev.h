@@ -313,6 +313,7 @@ struct QuadParams {
     long nx, ny;
     double lat0_bp, lon_bp, rp, Re;
     long j0;           // first cell row of the band (band-local output row 0)
+    long top_out_row;  // band-local row of dxq that holds the j = ny row (the band that owns it), else -1
     double guard_k;       // exactness guard of bp_point_fast
     unsigned* fix_count;  // number of cells handed to the literal fix-up ...
     unsigned* fix_list;   // ... and their band-local linear indices out_r*nx + ci
@@ -332,16 +333,77 @@ struct QuadRange {     // the part of the band one grid of strip workgroups eval
     long row_begin;    // cell rows [row_begin, row_end)
     long row_end;
     long rows_per_chunk;  // cell rows one wave walks (its first lattice row is recomputed: 1/((N-1)*rows_per_chunk) extra)
-    int top_row;       // 1: evaluate only dxq[ny][:] (exact j = ny lattice row) into band row out_row
-    long out_row;
     unsigned gy;       // workgroups along the rows
 };
 
 // row-only and column-only parts of the projection for every unique lattice row / column of the cap (OGG:126-127,
 // 41-46, 75-78), evaluated once per call instead of once per tile
 template <int N>
+OGG_DEV double quad_average_1d(const double* y) {  // OGG:207-222
+    if (N == 2) return (1.0 / 2.0) * (y[0] + y[1]);
+    if (N == 3) return (1.0 / 6.0) * (4.0 * y[1] + (y[0] + y[2]));
+    if (N == 4) return (1.0 / 12.0) * (5.0 * (y[1] + y[2]) + (y[0] + y[3]));
+    return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
+}
+
+template <int N>
+OGG_DEV double quad_weight_1d(int k) {  // w[k] of OGG:240 / 248, as selects (k may be a run-time value)
+    if (N == 4) return (k == 0 || k == 3) ? 1.0 : 5.0;
+    return (k == 0 || k == 4) ? 9.0 : ((k == 2) ? 64.0 : 49.0);
+}
+
+template <int N>
+__host__ __device__ inline unsigned tables_only_blocks(const QuadParams& p) {
+    return (unsigned)(((N - 1) * p.ny + 2 + (N - 1) * p.nx + 1 + 255) / 256);
+}
+
+// dxq[ny][:] -- the exact j = ny lattice row (OGG:183 for the last row of dxq), literal sequence -- depends on nothing but the cap's
+// parameters, so it rides with the tables (ONE lattice column per lane, the cell sums through wave shuffles) instead of waiting for
+// the tail launch behind the quadrature, where its four-columns-per-lane chain of libm calls was the longest thing in that launch.
+// A wave covers TOP_CELLS<N> cells = TOP_CELLS * (N-1) + 1 <= 64 lattice columns; 4 waves per workgroup.
+template <int N>
+constexpr int top_cells() { return 63 / (N - 1); }
+template <int N>
+inline unsigned top_row_blocks(const QuadParams& p) {
+    if (p.top_out_row < 0) return 0u;
+    const long waves = (p.nx + top_cells<N>() - 1) / top_cells<N>();
+    return (unsigned)((waves + 3) / 4);
+}
+
+template <int N>
+OGG_DEV void bipolar_top_row_body(const QuadParams& p, long w) {   // w: wave index
+    constexpr int M = N - 1, CW = top_cells<N>();
+    const int lane = threadIdx.x & 63;
+    const long c0 = w * CW;
+    if (c0 >= p.nx) return;   // wave-uniform
+    long u = M * c0 + lane;   // lattice column of this lane (the table's index)
+    if (u > M * p.nx) u = M * p.nx;
+    const double iv = lattice_node(p.q, (int)(u % M), u / M);
+    const double lon = p.lon_bp + (iv * 360.0) / (double)p.nx;                    // OGG:126
+    const BpCol c = bp_col(lon, p.lon_bp);
+    const double jv = lattice_node(p.q, 0, p.ny);                                 // first node of cell ny: j = ny exactly
+    const double latg = p.lat0_bp + (jv * (90 - p.lat0_bp)) / (double)p.ny;       // OGG:127
+    const BpRow r = bp_row(latg, p.rp);
+    double phis, rden, h_i, h_j;
+    bp_point(r, c, p.rp, phis, h_i, h_j, rden);
+    const double dx = h_i * 2 * kPi / (double)p.nx;                               // OGG:131
+    double y[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) y[k] = __shfl_down(dx, k);
+    const int cell = lane / M;
+    if (lane % M == 0 && cell < CW && c0 + cell < p.nx) p.dxq[p.top_out_row * p.nx + c0 + cell] = quad_average_1d<N>(y) * p.Re;
+}
+
+// row-only and column-only parts of the projection for every unique lattice row / column of the cap (OGG:126-127,
+// 41-46, 75-78), evaluated once per call instead of once per tile; the workgroups behind them: the j = ny row of dxq
+template <int N>
 OGG_DEV void bipolar_tables_body(const QuadParams& p, long bx) {
     constexpr int M = N - 1;
+    const long nb_tab = tables_only_blocks<N>(p);
+    if (bx >= nb_tab) {
+        bipolar_top_row_body<N>(p, (bx - nb_tab) * 4 + (threadIdx.x >> 6));
+        return;
+    }
     BpRow* row_tab = const_cast<BpRow*>(p.row_tab);
     BpCol* col_tab = const_cast<BpCol*>(p.col_tab);
     const long k = bx * blockDim.x + threadIdx.x;
@@ -352,7 +414,7 @@ OGG_DEV void bipolar_tables_body(const QuadParams& p, long bx) {
         if (k == M * p.ny)
             jv = (double)p.ny - 0.001;  // OGG:146-147: last node of cell ny-1
         else if (k == M * p.ny + 1)
-            jv = lattice_node(p.q, 0, p.ny);  // first node of cell ny: j = ny exactly (feeds dxq[ny])
+            jv = lattice_node(p.q, 0, p.ny);  // first node of cell ny: j = ny exactly
         else
             jv = lattice_node(p.q, (int)(k % M), k / M);
         const double latg = p.lat0_bp + (jv * (90 - p.lat0_bp)) / (double)p.ny;   // OGG:127
@@ -371,22 +433,8 @@ __global__ __launch_bounds__(256) void bipolar_tables_kernel(QuadParams p) {
 }
 
 template <int N>
-inline unsigned tables_blocks(const QuadParams& p) {
-    return (unsigned)(((N - 1) * p.ny + 2 + (N - 1) * p.nx + 1 + 255) / 256);
-}
-
-template <int N>
-OGG_DEV double quad_average_1d(const double* y) {  // OGG:207-222
-    if (N == 2) return (1.0 / 2.0) * (y[0] + y[1]);
-    if (N == 3) return (1.0 / 6.0) * (4.0 * y[1] + (y[0] + y[2]));
-    if (N == 4) return (1.0 / 12.0) * (5.0 * (y[1] + y[2]) + (y[0] + y[3]));
-    return (1.0 / 180.0) * (64.0 * y[2] + (49.0 * (y[1] + y[3])) + 9.0 * (y[0] + y[4]));
-}
-
-template <int N>
-OGG_DEV double quad_weight_1d(int k) {  // w[k] of OGG:240 / 248, as selects (k may be a run-time value)
-    if (N == 4) return (k == 0 || k == 3) ? 1.0 : 5.0;
-    return (k == 0 || k == 4) ? 9.0 : ((k == 2) ? 64.0 : 49.0);
+inline unsigned tables_blocks(const QuadParams& p) {   // table workgroups + the workgroups of the j = ny row
+    return tables_only_blocks<N>(p) + top_row_blocks<N>(p);
 }
 
 // A wave owns a vertical strip of 63 cells (lane 63 is a halo lane: the first cell of the next strip) and walks up the
@@ -492,11 +540,6 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
     double rp2p = p.rp2p;
     asm volatile("" : "+v"(rp2p));   // held in a vector register for the whole walk (else re-copied from its scalar register per point)
     RowEval<N, MODE> cur;
-    if (rg.top_row) {  // dxq[ny][:] from the exact j = ny lattice row
-        eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * p.ny + 1], col, rp2p, true, cur);
-        if (cell_lane) p.dxq[rg.out_row * p.nx + ci] = quad_average_1d<N>(cur.dx) * p.Re;
-        return;
-    }
     const long r0 = rg.row_begin + by * rg.rows_per_chunk;
     const long r1 = (r0 + rg.rows_per_chunk < rg.row_end) ? r0 + rg.rows_per_chunk : rg.row_end;
     eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, rp2p, true, cur);
@@ -511,8 +554,10 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
 #pragma unroll((N <= 3 || MODE == QM_FAST) ? N : 1)
         for (int jj = 0; jj < N; ++jj) {
             if (jj > 0) {
-                // the top row of this cell row is the bottom row of the next one (not needed past the end of the chunk)
-                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, rp2p, jj == M && c + 1 < r1, cur);
+                // the top row of this cell row is the bottom row of the next one.  Every cell-edge lattice row is evaluated in the
+                // edge form (dx and dy separately), also the last one of a chunk, whose dx nobody reads: the area of a cell must not
+                // depend on where the chunks -- hence the bands of a sharded run -- end
+                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, rp2p, jj == M, cur);
                 guarded |= cur.guarded;
             }
             const double wj = quad_weight_1d<N>(jj);
@@ -567,19 +612,11 @@ __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams 
 // in the reference's order; overwrites the cell's dxq, dyq, daq (and dyq[.][nx] for the last cell of a row).  A cell is
 // re-evaluated iff one of ITS points is guarded, which depends on the cell alone: the result does not depend on tiling or
 // banding.
-//
-// The same launch evaluates dxq[ny][:] (the exact j = ny lattice row, literal as well) in its first n_top workgroups, one
-// strip each; top.top_row must be 1.
 template <int N>
-__global__ __launch_bounds__(64) void bipolar_quad_tail_kernel(QuadParams p, QuadRange top, unsigned n_top, unsigned do_fixup) {
+__global__ __launch_bounds__(64) void bipolar_quad_tail_kernel(QuadParams p) {
     constexpr int M = N - 1;
     __shared__ double sdx[64], sdy[64];
-    if (blockIdx.x < n_top) {
-        bipolar_quad_body<N, QM_LITERAL>(p, top, blockIdx.x, 0);
-        return;
-    }
-    if (!do_fixup) return;
-    const unsigned bid = blockIdx.x - n_top, nblk = gridDim.x - n_top;
+    const unsigned bid = blockIdx.x, nblk = gridDim.x;
     const unsigned count = *p.fix_count;
     const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
     const int jj = (q < N * N) ? q / N : 0, ii = (q < N * N) ? q % N : 0;
@@ -690,8 +727,8 @@ size_t quad_workspace_bytes(long nx, long ny, long n_cell_rows) {
 struct QuadPlan {
     QuadParams p;
     unsigned gx;                 // strip workgroups along the columns
-    bool has_fast, has_guard, has_top;
-    QuadRange fast, guard, top;
+    bool has_fast, has_guard, has_top;   // has_top: the band owns the j = ny row of dxq (evaluated with the tables)
+    QuadRange fast, guard;
 };
 
 template <int N>
@@ -708,6 +745,7 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     p.fix_count = fix_count;
     p.fix_list = fix_count + 4;
     p.guard_k = guard_k;
+    p.top_out_row = (n_dx_rows > n_cell_rows) ? n_cell_rows : -1;
     const double rp2 = p.rp * p.rp;
     p.sx = (2 * kPi) / (double)p.nx, p.sy = ((90 - p.lat0_bp) * kPi180) / (double)p.ny;
     p.rp2p = 1 + rp2, p.rp2m = 1 - rp2, p.rp2x4 = 4 * rp2;
@@ -743,22 +781,16 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     out.has_top = n_dx_rows > n_cell_rows;
     if (out.has_fast) out.fast = range(lo, hi < jg ? hi : jg);
     if (out.has_guard) out.guard = range(lo > jg ? lo : jg, hi);
-    out.top = QuadRange{};
-    out.top.top_row = 1;  // dxq[ny][:] from the exact j = ny lattice row: literal sequence
-    out.top.out_row = n_cell_rows;
-    out.top.gy = 1;
     return OGG_OK;
 }
 
 constexpr unsigned FIXUP_BLOCKS = 2048;
 
-// fix-up of the guarded cells and / or the j = ny row of dxq, whichever this band has
+// fix-up of the guarded cells, if this band has rows that carry the guard
 template <int N>
 int launch_quad_tail(const QuadPlan& q, hipStream_t s) {
-    const unsigned n_top = q.has_top ? (unsigned)((q.p.nx + QS_CELLS - 1) / QS_CELLS) : 0u;
-    const unsigned n_fix = q.has_guard ? FIXUP_BLOCKS : 0u;
-    if (n_top + n_fix == 0) return OGG_OK;
-    bipolar_quad_tail_kernel<N><<<n_top + n_fix, 64, 0, s>>>(q.p, q.top, n_top, q.has_guard ? 1u : 0u);
+    if (!q.has_guard) return OGG_OK;
+    bipolar_quad_tail_kernel<N><<<FIXUP_BLOCKS, 64, 0, s>>>(q.p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }

@@ -284,11 +284,11 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         const double ni = (double)(ni1 - 1);
         const double mesh_bytes = have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0;
         const double bq_bytes = have_quad ? 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) : 0.0;
-        alg_bytes4[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes);
+        alg_bytes4[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes) + ((have_quad && qp.has_top) ? 8.0 * ni : 0.0);   // + dxq[ny]
         alg_bytes4[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + bq_bytes + mesh_bytes + (have_dp ? dpole_mesh_bytes(*scap) : 0.0) +
                                        ((have_dquad && !dq_literal) ? dpole_quad_bytes(*scap) : 0.0)
                                  : 0.0;
-        alg_bytes4[2] = (have_quad && qp.has_top) ? 8.0 * ni : 0.0;
+        alg_bytes4[2] = 0.0;   // the tail rewrites cells launch B has written: no bytes of its own
         alg_bytes4[3] = dq_literal ? dpole_quad_bytes(*scap) : 0.0;
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap && !have_dp);

@@ -220,6 +220,21 @@ def test_bipolar_quad_vs_oracle(ogg, Ni, Nj, lat0):
         assert max(abs(e) for e in err) < 1e-9
 
 
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_bipolar_quad_does_not_depend_on_chunking(ogg, order, monkeypatch):
+    """A wave walks a chunk of cell rows; where the chunks end depends on the size of the band (OGG_QUAD_TARGET_WAVES, band sharding).
+    The value of a cell must not: every chunk length gives the same bits (1 row per chunk ... the whole cap in one chunk)."""
+    Ni, Nj, lat0 = 1440, 96, 64.05895973
+    rp = np.tan(0.5 * (90 - lat0) * orc.PI_180)
+    got = []
+    for target in ("1000000", "700", "97", "1"):
+        monkeypatch.setenv("OGG_QUAD_TARGET_WAVES", target)
+        got.append(ogg.bipolar_cap_metrics_quad_fast(order, Ni, Nj, lat0, -300.0, rp))
+    for g in got[1:]:
+        for a, b in zip(got[0], g):
+            assert np.array_equal(a, b)
+
+
 def test_bipolar_quad_full_size_r8_by_zone(ogg):
     """BASELINE config 2's cap (5760 x 960 cells) against the oracle, in bands from the joint to the pole: the algebraic
     per-point form, the guarded rows and the cells re-evaluated by the literal fix-up must all stay at the same level."""
