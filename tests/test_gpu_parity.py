@@ -220,6 +220,16 @@ def test_bipolar_quad_vs_oracle(ogg, Ni, Nj, lat0):
         assert max(abs(e) for e in err) < 1e-9
 
 
+def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
+    got = []
+    for rows in ("8", "1", "5", "32"):
+        monkeypatch.setenv("OGG_MESH_ROWS", rows)
+        got.append(ogg.generate_bipolar_cap_mesh(720, 61, 64.05895973, -300.0))
+    for g in got[1:]:
+        for a, b in zip(got[0][:2], g[:2]):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("order", [2, 3, 4, 5])
 def test_bipolar_quad_does_not_depend_on_chunking(ogg, order, monkeypatch):
     """A wave walks a chunk of cell rows; where the chunks end depends on the size of the band (OGG_QUAD_TARGET_WAVES, band sharding).
