@@ -5,7 +5,28 @@ namespace ogg {
 QuadNodes quad_nodes_host(int order) { return make_nodes(order); }
 }  // namespace ogg
 
+namespace {
+__global__ void asin_unit_check_kernel(long n, const double* __restrict__ x, unsigned long long* n_diff) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool diff = false;
+    if (k < n) {
+        const double a = asin_unit(x[k]), b = asin(x[k]);
+        diff = __double_as_longlong(a) != __double_as_longlong(b);
+    }
+    const unsigned long long m = __ballot(diff);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_diff, (unsigned long long)__popcll(m));
+}
+}  // namespace
+
 extern "C" {
+
+int ogg_asin_unit_check_dev(long n, const double* x, unsigned long long* n_diff, void* stream) {
+    OGG_REQUIRE(n >= 0 && x && n_diff, OGG_EARG, "ogg_asin_unit_check: bad argument");
+    if (n == 0) return OGG_OK;
+    asin_unit_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(n, x, n_diff);
+    OGG_LAUNCH_CHECK();
+    return OGG_OK;
+}
 
 int ogg_bipolar_projection_dev(long n, const double* lamg, const double* phig, double lon_bp, double rp, int metrics_only,
                                double* lams, double* phis, double* h_i_inv, double* h_j_inv, void* stream) {

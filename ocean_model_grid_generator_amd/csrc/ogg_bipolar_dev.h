@@ -131,11 +131,71 @@ OGG_DEV bool bp_point_fast(const BpRow& r, double b1, double bb1, const BpCol& c
     return (uid * uid > kc * (Yn * Yn)) || (ujd * ujd > kc * (Xn * Xn));
 }
 
+// asin(x) for 0 <= x <= 1, the SAME bits as ocml's asin (ROCm 7.2 device library, __ocml_asin_f64: one 12-coefficient polynomial in
+// x^2 below 0.5 and in (1-x)/2 above, there with the square root and the reconstruction pi/2 - 2 (s + s p) in double-double) --
+// restated operation for operation so that its coefficients can be scalar operands (horner_scalar: 12 instead of 36 vector instructions
+// for the polynomial).  Bit-identity with asin() is a test (test_asin_unit_equals_library_asin: 4e7 arguments, the ends, the
+// neighbours of 0.5), so the parity numbers of the mesh are those of ocml's asin.
+__constant__ double kAsinPoly[12] = {0x1.5555555555380p-3, 0x1.333333336fd5bp-4, 0x1.6db6db41ce4bdp-5, 0x1.f1c72c668963fp-6,
+                                     0x1.6e89f0a0adacfp-6, 0x1.1c6c111dccb70p-6, 0x1.c6fa84b77012bp-7, 0x1.8ed60a300c8d2p-7,
+                                     0x1.ab3a098a70509p-8, 0x1.4052137024d6ap-6, -0x1.0a5a378a05eafp-6, 0x1.059859fea6a70p-5};
+
+OGG_DEV double asin_unit(double x) {
+    const bool hi = x >= 0.5;
+    const double h = fma(x, -0.5, 0.5);          // (1 - x) / 2
+    const double r = hi ? h : x * x;
+    const double p = r * horner_scalar<12>(kAsinPoly, r);
+    double v = fma(x, p, x);
+    if (hi) {                                    // (a wave of the mesh almost always has such lanes)
+        // s = sqrt(h): seed, one coupled step, one residual step
+        const double y = __builtin_amdgcn_rsq(h);
+        const double g0 = h * y, h0 = y * 0.5;
+        const double e = fma(-h0, g0, 0.5);
+        const double h1 = fma(h0, e, h0), g1 = fma(g0, e, g0);
+        const double d = fma(-g1, g1, h);
+        const double s0 = fma(d, h1, g1);
+        const bool zero = h == 0.0;
+        const double s = zero ? h : s0;
+        // tail of the root: (h - s^2) / (2 s) in double-double
+        const double ss = s * s;
+        const double sse = fma(s, s, -ss);
+        const double t0 = h - ss;
+        const double t1 = ((h - t0) - ss) - sse;
+        const double num = t0 + t1;
+        const double den = s * 2.0;
+        const double rc0 = __builtin_amdgcn_rcp(den);
+        const double rc1 = fma(fma(-den, rc0, 1.0), rc0, rc0);
+        const double rc = fma(fma(-den, rc1, 1.0), rc1, rc1);
+        const double q0 = num * rc;
+        const double q = fma(fma(-den, q0, num), rc, q0);
+        const double c = zero ? 0.0 : q;
+        const double sh = s + c;
+        const double sl = c - (sh - s);
+        // (sh + sl) * p, then + (sh + sl), in double-double
+        const double ph = p * sh;
+        const double pl = fma(sl, p, fma(sh, p, -ph));
+        const double a = ph + pl;
+        const double al = pl - (a - ph);
+        const double b = sh + a;
+        const double bl = a - (b - sh);
+        const double w = (sl + al) + bl;
+        const double u = b + w;
+        const double ul = w - (u - b);
+        // pi/4 - (u + ul), doubled
+        constexpr double pio4 = 0x1.921fb54442d18p-1, pio4_lo = 0x1.1a62633145c07p-55;
+        const double z = pio4 - u;
+        const double zl = (((pio4 - z) - u) + pio4_lo) - ul;
+        const double res = z + zl;
+        v = (x == 1.0) ? 0x1.921fb54442d18p+0 : res + res;
+    }
+    return v;
+}
+
 // lams of OGG:50-64
 OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double rden, double lamg, double lon_bp) {
     double B = c.sinla * sqrt(rden);
     if (fabs(r.beta2_inv) > kHuge) B = 0.0;
-    double lamc = div_pi180(asin(B));
+    double lamc = div_pi180(asin_unit(B));   // B in [0, 1]
     const double dl = lamg - lon_bp;
     if ((dl > 90) && (dl <= 180)) lamc = 180 - lamc;
     if ((dl > 180) && (dl <= 270)) lamc = 180 + lamc;

@@ -220,6 +220,25 @@ def test_bipolar_quad_vs_oracle(ogg, Ni, Nj, lat0):
         assert max(abs(e) for e in err) < 1e-9
 
 
+def test_asin_unit_equals_library_asin(hip):
+    """The mesh takes asin from a restatement of the device library's own algorithm (coefficients as scalar operands): every bit must
+    agree with asin(), on 4e7 arguments of [0, 1] incl. the ends, the neighbours of 0.5 and of 1, and tiny values."""
+    import torch
+    from ocean_model_grid_generator_amd import _lib as L
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    n = 40_000_000
+    x = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g)
+    x[: n // 8] = x[: n // 8] ** 8                          # small arguments
+    x[n // 8: n // 4] = 1.0 - x[n // 8: n // 4] ** 6        # next to 1
+    special = torch.tensor([0.0, 1.0, 0.5, np.nextafter(0.5, 0), np.nextafter(0.5, 1), np.nextafter(1.0, 0), 5e-324, 1e-300, 2.0 ** -27,
+                            2.0 ** -540], dtype=torch.float64, device="cuda:0")
+    x[-special.numel():] = special
+    n_diff = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    L.call("ogg_asin_unit_check_dev", n, x.data_ptr(), n_diff.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(n_diff.item()) == 0
+
+
 def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
     got = []
     for rows in ("8", "1", "5", "32"):
