@@ -314,10 +314,10 @@ int ogg_fill_dev(long n, double value, double* out, void* stream);
 /* Byte-swap-on-copy for write_nc's big-endian output (NetCDF classic, OGG:773-829): dst[k] = bswap64(src[k]), k < n.  src is device
  * memory; dst is device memory or pinned host memory (hipHostMalloc / torch pin_memory), into which the kernel stores directly. */
 int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream);
-/* Self-test of the one library function the bipolar mesh restates (asin on [0, 1] with scalar coefficients, ogg_bipolar_dev.h): the
- * number of k < n for which it differs IN ANY BIT from the device library's asin(x[k]) is ADDED to *n_diff (device memory, 8 bytes,
- * zeroed by the caller).  x in [0, 1]. */
-int ogg_asin_unit_check_dev(long n, const double* x, unsigned long long* n_diff, void* stream);
+/* Self-test of the device-library functions the kernels restate with their coefficients as scalar operands (ogg_math.h,
+ * ogg_bipolar_dev.h): which = 0: asin on [0, 1] (x); 1: atan (x, any); 2: atan2(y, x), finite.  The number of k < n for which the
+ * restatement differs IN ANY BIT from the library's own function is ADDED to *n_diff (device memory, 8 bytes, zeroed by the caller). */
+int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream);
 /* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:
  * out5 = { sum(area), sum(dy[:, col_a]), sum(dy[:, col_b]) (0 when col_b < 0), sum(dx[0, :]) if want_first_row,
  * sum(dx[n_dx_rows-1, :]) if want_last_row }.  dx: n_dx_rows x ni, dy: n_cell_rows x (ni+1), area: n_cell_rows x ni; out5 is a

@@ -130,7 +130,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],
     "ogg_bswap64_dev": [c_long, c_void_p, c_void_p, c_void_p],
-    "ogg_asin_unit_check_dev": [c_long, c_void_p, c_void_p, c_void_p],
+    "ogg_libm_check_dev": [c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_metrics_sums_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p],
     "ogg_event_create": [ctypes.POINTER(c_void_p)],
     "ogg_event_destroy": [c_void_p],

@@ -6,11 +6,17 @@ QuadNodes quad_nodes_host(int order) { return make_nodes(order); }
 }  // namespace ogg
 
 namespace {
-__global__ void asin_unit_check_kernel(long n, const double* __restrict__ x, unsigned long long* n_diff) {
+__global__ void libm_check_kernel(int which, long n, const double* __restrict__ x, const double* __restrict__ y, unsigned long long* n_diff) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool diff = false;
     if (k < n) {
-        const double a = asin_unit(x[k]), b = asin(x[k]);
+        double a, b;
+        if (which == 0)
+            a = asin_unit(x[k]), b = asin(x[k]);
+        else if (which == 1)
+            a = atan_lib(x[k]), b = atan(x[k]);
+        else
+            a = atan2_lib(y[k], x[k]), b = atan2(y[k], x[k]);
         diff = __double_as_longlong(a) != __double_as_longlong(b);
     }
     const unsigned long long m = __ballot(diff);
@@ -20,10 +26,10 @@ __global__ void asin_unit_check_kernel(long n, const double* __restrict__ x, uns
 
 extern "C" {
 
-int ogg_asin_unit_check_dev(long n, const double* x, unsigned long long* n_diff, void* stream) {
-    OGG_REQUIRE(n >= 0 && x && n_diff, OGG_EARG, "ogg_asin_unit_check: bad argument");
+int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream) {
+    OGG_REQUIRE(which >= 0 && which <= 2 && n >= 0 && x && n_diff && (which != 2 || y), OGG_EARG, "ogg_libm_check: bad argument");
     if (n == 0) return OGG_OK;
-    asin_unit_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(n, x, n_diff);
+    libm_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(which, n, x, y, n_diff);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
 }

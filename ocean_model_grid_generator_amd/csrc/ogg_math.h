@@ -161,19 +161,93 @@ OGG_DEV coef_table_t scalar_table(const double* t) {
     return p;
 }
 
-// c[N-1] z^(N-1) + ... + c[1] z + c[0], Horner, coefficients from a __constant__ table through scalar registers
+// N coefficients of a __constant__ table in scalar registers.  load() once, eval() as often as wanted, keep() behind the last use
+// (all three in the same function after inlining).  A kernel that evaluates one polynomial many times per iteration of a long loop
+// (the displaced-pole quadrature: 16 arctangents per lattice point) loads ONCE in front of the loop and keeps behind it -- loaded per
+// use, sixteen sets of forty scalar registers want to be in flight at once and spill into vector-register lanes.
+template <int N>
+struct ScalarPoly {
+    double k[N];
+    OGG_DEV void load(const double* table) {
+        const coef_table_t c = scalar_table(table);
+#pragma unroll
+        for (int i = 0; i < N; ++i) k[i] = c[i];
+    }
+    // k[N-1] z^(N-1) + ... + k[1] z + k[0], Horner
+    OGG_DEV double eval(double z) const {
+        double p = k[N - 1];
+#pragma unroll
+        for (int i = N - 2; i >= 0; --i) p = fma(p, z, k[i]);
+        return p;
+    }
+    OGG_DEV void keep() const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" ::"s"(k[i]));
+    }
+};
+
+// one-shot form: load, evaluate, keep
 template <int N>
 OGG_DEV double horner_scalar(const double* table, double z) {
-    const coef_table_t c = scalar_table(table);
-    double k[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) k[i] = c[i];
-    double p = k[N - 1];
-#pragma unroll
-    for (int i = N - 2; i >= 0; --i) p = fma(p, z, k[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" ::"s"(k[i]));
+    ScalarPoly<N> c;
+    c.load(table);
+    const double p = c.eval(z);
+    c.keep();
     return p;
+}
+
+// atan and atan2 with the SAME bits as the device library's (ROCm 7.2 ocml: __ocml_atan_f64, __ocml_atan2_f64 and their shared
+// 20-coefficient odd polynomial __ocmlpriv_atanred_f64, read from the library's bitcode), restated operation for operation so that the
+// coefficients are scalar operands: 20 instead of 60 vector instructions per polynomial.  atan_lib: all arguments.  atan2_lib: FINITE
+// arguments (the library's extra selects for infinities and NaNs are left out; signed zeros and atan2(0, 0) are kept).  Bit-identity
+// with atan() / atan2() is tested on 4e7 arguments each (ogg_libm_check_dev), so every parity number measured with ocml's functions
+// stands.
+static __constant__ double kAtanRed[20] = {-0x1.5555555555523p-2, 0x1.99999999952ccp-3,  -0x1.2492492376b7dp-3, 0x1.c71c717e1913cp-4,
+                                    -0x1.745d119378e4fp-4, 0x1.3b13657b87036p-4,  -0x1.110e48b207f05p-4, 0x1.e1bb48427b883p-5,
+                                    -0x1.ae5ce6a214619p-5, 0x1.82d5d6ef28734p-5,  -0x1.59976e82d3ff0p-5, 0x1.2c15b5711927ap-5,
+                                    -0x1.e9ae6fc27006ap-6, 0x1.67e295f08b19fp-6,  -0x1.c6ea4a57d9582p-7, 0x1.d6d43a595c56fp-8,
+                                    -0x1.7952daf56de9bp-9, 0x1.b2bb069efb384p-11, -0x1.3e260bd3237f4p-13, 0x1.ba404b5e68a13p-17};
+
+typedef ScalarPoly<20> AtanCoefs;   // AtanCoefs c; c.load(kAtanRed); ... atan2_lib(y, x, c) ...; c.keep();
+
+OGG_DEV double atanred_lib(double v, const AtanCoefs& c) {   // |v| <= 1
+    const double t = v * v;
+    return fma(v, t * c.eval(t), v);
+}
+
+OGG_DEV double atan_lib(double x, const AtanCoefs& c) {
+    const double v = fabs(x);
+    const bool g = v > 1.0;
+    const double a = atanred_lib(g ? 1.0 / v : v, c);
+    const double r = g ? fma(0x1.dd9ad336a0500p-1, 0x1.af154eeb562d6p+0, -a) : a;   // pi/2 as an exact product
+    return copysign(r, x);
+}
+
+OGG_DEV double atan2_lib(double y, double x, const AtanCoefs& c) {   // finite arguments
+    const double ay = fabs(y), ax = fabs(x);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    double a = atanred_lib(mn / mx, c);
+    const bool xneg = __double2hiint(x) < 0;     // the sign BIT: -0.0 counts
+    a = (ax < ay) ? 0x1.921fb54442d18p+0 - a : a;
+    a = xneg ? 0x1.921fb54442d18p+1 - a : a;
+    a = (y == 0.0) ? (xneg ? 0x1.921fb54442d18p+1 : 0.0) : a;
+    return copysign(a, y);
+}
+
+// one-shot forms (coefficients loaded for this one call)
+OGG_DEV double atan_lib(double x) {
+    AtanCoefs c;
+    c.load(kAtanRed);
+    const double r = atan_lib(x, c);
+    c.keep();
+    return r;
+}
+OGG_DEV double atan2_lib(double y, double x) {
+    AtanCoefs c;
+    c.load(kAtanRed);
+    const double r = atan2_lib(y, x, c);
+    c.keep();
+    return r;
 }
 
 // Neighbour lanes of a wave64 through DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130): two VALU moves per

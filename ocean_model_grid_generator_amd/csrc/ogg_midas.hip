@@ -88,11 +88,11 @@ OGG_DEV double angle_of(const RowVals& v, long i, long ni1) {
     const double c = cos(v.yc * kPi180);
     double a;
     if (i == 0)
-        a = atan2(v.yr - v.yc, (v.xr - v.xc) * c);
+        a = atan2_lib(v.yr - v.yc, (v.xr - v.xc) * c);
     else if (i == ni1 - 1)
-        a = atan2(v.yc - v.yl, (v.xc - v.xl) * c);
+        a = atan2_lib(v.yc - v.yl, (v.xc - v.xl) * c);
     else
-        a = atan2(v.yr - v.yl, (v.xr - v.xl) * c);
+        a = atan2_lib(v.yr - v.yl, (v.xr - v.xl) * c);
     return div_pi180(a);
 }
 

@@ -220,11 +220,20 @@ def test_bipolar_quad_vs_oracle(ogg, Ni, Nj, lat0):
         assert max(abs(e) for e in err) < 1e-9
 
 
+def _libm_check(which, x, y=None):
+    import torch
+    from ocean_model_grid_generator_amd import _lib as L
+    n_diff = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    L.call("ogg_libm_check_dev", which, x.numel(), x.data_ptr(), y.data_ptr() if y is not None else None, n_diff.data_ptr(),
+           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return int(n_diff.item())
+
+
 def test_asin_unit_equals_library_asin(hip):
     """The mesh takes asin from a restatement of the device library's own algorithm (coefficients as scalar operands): every bit must
     agree with asin(), on 4e7 arguments of [0, 1] incl. the ends, the neighbours of 0.5 and of 1, and tiny values."""
     import torch
-    from ocean_model_grid_generator_amd import _lib as L
     g = torch.Generator(device="cuda:0").manual_seed(11)
     n = 40_000_000
     x = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g)
@@ -233,10 +242,39 @@ def test_asin_unit_equals_library_asin(hip):
     special = torch.tensor([0.0, 1.0, 0.5, np.nextafter(0.5, 0), np.nextafter(0.5, 1), np.nextafter(1.0, 0), 5e-324, 1e-300, 2.0 ** -27,
                             2.0 ** -540], dtype=torch.float64, device="cuda:0")
     x[-special.numel():] = special
-    n_diff = torch.zeros(1, dtype=torch.int64, device="cuda:0")
-    L.call("ogg_asin_unit_check_dev", n, x.data_ptr(), n_diff.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert int(n_diff.item()) == 0
+    assert _libm_check(0, x) == 0
+
+
+def test_atan_atan2_restatements_equal_the_library(hip):
+    """atan_lib / atan2_lib (ogg_math.h) against the device library's atan / atan2: every bit, 4e7 arguments each over 600 binades,
+    both signs, signed zeros, equal magnitudes, arguments next to 1."""
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(12)
+    n = 40_000_000
+
+    def spread(k):
+        m = torch.rand(k, dtype=torch.float64, device="cuda:0", generator=g) + 1.0
+        e = torch.randint(-300, 300, (k,), device="cuda:0", generator=g).to(torch.float64)
+        sgn = torch.randint(0, 2, (k,), device="cuda:0", generator=g).to(torch.float64) * 2 - 1
+        return sgn * m * torch.exp2(e)
+
+    x = spread(n)
+    x[: n // 4] = (torch.rand(n // 4, dtype=torch.float64, device="cuda:0", generator=g) * 4 - 2)       # around +-1
+    sp = torch.tensor([0.0, -0.0, 1.0, -1.0, np.nextafter(1.0, 2), np.nextafter(1.0, 0), 5e-324, -5e-324, 1.7e308, -1.7e308,
+                       float("inf"), float("-inf")], dtype=torch.float64, device="cuda:0")
+    x[-sp.numel():] = sp
+    assert _libm_check(1, x) == 0
+    y = spread(n)
+    x = spread(n)
+    q = n // 4
+    x[:q] = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) * 2 - 1                     # comparable magnitudes
+    y[:q] = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) * 2 - 1
+    y[q: q + 1000] = x[q: q + 1000]                                                                      # |y| == |x|
+    fy = torch.tensor([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, 0.0, -0.0, 3.0, 5e-324], dtype=torch.float64, device="cuda:0")
+    fx = torch.tensor([0.0, 0.0, -0.0, -0.0, 0.0, -0.0, 2.0, -2.0, -5e-324, 1.7e308], dtype=torch.float64, device="cuda:0")
+    y[-fy.numel():] = fy
+    x[-fx.numel():] = fx
+    assert _libm_check(2, x, y) == 0
 
 
 def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
