@@ -94,56 +94,22 @@ OGG_DEV double cabs_np(cplx w) {
     return a * sqrt(fma(r, r, 1.0));
 }
 
-// 1/x, 1/sqrt(x) and sqrt(x) for NORMAL, positive x from the hardware seed (v_rcp_f64 / v_rsq_f64, relative error e <= 2^-26
-// measured, scripts/microbench/rcp_rsq_accuracy.hip): no denormal scaling, no fix-up.  Only used where a kernel documents that it
-// departs from the reference's literal operation sequence (bp_point_fast, the mesh's tan(acos(A)/2), atan2_angle); everything else
-// uses IEEE division and sqrt.
-//   *_nr: two Newton steps (quadratic: e -> 1.5 e^2 -> rounding level).
-//   *_c3: ONE third-order step -- 1/x = y (1 + e + e^2 + ...), x^(-1/2) = y (1 + e/2 + 3 e^2/8 + ...) with e = 1 - x y (resp. 1 - x y^2)
-//         exact from the fma -- which leaves e^3 = 2^-78 of truncation: 3 / 5 instructions after the seed instead of 4 / 7, <= 1 ulp
-//         (measured in the same micro-benchmark).
-OGG_DEV double rcp_nr(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-    return fma(y, e, y);
-}
-
+// 1/x and 1/sqrt(x) for NORMAL, positive x from the hardware seed (v_rcp_f64 / v_rsq_f64, relative error e <= 2^-24 measured,
+// scripts/microbench/rcp_rsq_accuracy.hip) and ONE third-order step -- 1/x = y (1 + e + e^2 + ...), x^(-1/2) = y (1 + e/2 + 3 e^2/8 + ...)
+// with e = 1 - x y (resp. 1 - x y^2) exact from the fma -- which leaves e^3 = 2^-72 of truncation: 0.5 / 1.0 ulp at worst over 1.7e7
+// operands of 680 binades (two Newton steps: 0.5 / 1.75 ulp and one / two more instructions; that micro-benchmark keeps them for
+// comparison).  No denormal scaling, no fix-up.  Only used where a kernel documents that it departs from the reference's literal
+// operation sequence (bp_point_fast, the mesh's tan(acos(A)/2), atan2_angle); everything else uses IEEE division and sqrt.
 OGG_DEV double rcp_c3(double x) {
     const double y = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, y, 1.0);
     return fma(y, fma(e, e, e), y);
 }
 
-OGG_DEV double rsqrt_nr(double x) {  // 1/sqrt(x), normal positive x
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = y * fma(-hx * y, y, 1.5);
-    return y * fma(-hx * y, y, 1.5);
-}
-
 OGG_DEV double rsqrt_c3(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-(x * y), y, 1.0);
     return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-
-OGG_DEV double sqrt_nr(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    const double h = 0.5 * y;          // 1/(2 sqrt x) to ~2^-26: enough for the last step, which only scales a 2^-52 residual
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    const double d = fma(-g, g, x);
-    return fma(d, h, g);
-}
-
-OGG_DEV double sqrt_c3(double x) {     // g = x y is sqrt(x) (1 - e)^(1/2) up to its own rounding, which the step sees through e
-    const double y = __builtin_amdgcn_rsq(x);
-    const double g = x * y;
-    const double e = fma(-g, y, 1.0);
-    return fma(g * e, fma(e, 0.375, 0.5), g);
 }
 
 // Polynomial coefficients as SCALAR operands.  A 64-bit literal cannot be an operand of a gfx9 VALU instruction: the compiler

@@ -9,6 +9,37 @@
 
 #include "ogg_math.h"
 
+namespace ogg {   // the Newton variants the kernels used before the third-order steps, kept here for comparison
+OGG_DEV double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+OGG_DEV double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    return y * fma(-hx * y, y, 1.5);
+}
+OGG_DEV double sqrt_nr(double x) {   // one coupled step + one residual step
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+OGG_DEV double sqrt_c3(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    const double e = fma(-g, y, 1.0);
+    return fma(g * e, fma(e, 0.375, 0.5), g);
+}
+}  // namespace ogg
+
 constexpr int NV = 9;
 
 __global__ void k(const double* x, double* o, int n) {
