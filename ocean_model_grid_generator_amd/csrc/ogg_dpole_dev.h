@@ -423,7 +423,7 @@ OGG_DEV double homogeneous_arc(const Hom& a, const Hom& b) {
     double th = t * fma(q, fma(q, 1.0 / 5.0, -1.0 / 3.0), 1.0);
     // grids so coarse that two probes are more than 1e-3 rad apart (a few dozen columns): the whole wave takes the library atan, behind a
     // wave-uniform branch that the fine grids never enter
-    if (__builtin_expect(__ballot(t >= 1e-3) != 0ull, 0)) th = (t >= 1e-3) ? atan(t) : th;
+    if (__builtin_expect(__ballot(t >= 1e-3) != 0ull, 0)) th = (t >= 1e-3) ? atan_lib(t) : th;   // the library's atan, bit for bit (ogg_math.h)
     return th;
 }
 
