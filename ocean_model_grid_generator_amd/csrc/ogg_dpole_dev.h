@@ -127,19 +127,25 @@ OGG_DEV double qavg_1d(const double* y) {  // OGG:207-222
 // result is the correctly rounded value up to the rounding of the last fma (<= 0.5000001 ulp) -- inside the <1 ulp band of
 // any libm, at 5 instructions instead of ocml's range-reduced sin / table-free asin.  The haversine of two probes that are
 // 2e-6 rad apart only ever sees such arguments; anything larger goes to ocml.
+// the library functions behind the range-specialised forms below, out of line: inlined, the literals of their polynomials (a few dozen
+// doubles) are hoisted out of the quadrature's loop into vector registers for branches that a fine grid never takes
+__device__ __attribute__((noinline)) double lib_sin(double x) { return sin(x); }
+__device__ __attribute__((noinline)) double lib_asin(double x) { return asin(x); }
+__device__ __attribute__((noinline)) double lib_cos(double x) { return cos(x); }
+
 OGG_DEV double sin_tiny(double x) {
     if (fabs(x) < 0x1p-13) {
         const double x2 = x * x;
         return fma(x * x2, fma(x2, 1.0 / 120.0, -1.0 / 6.0), x);
     }
-    return sin(x);
+    return lib_sin(x);
 }
 OGG_DEV double asin_tiny(double x) {
     if (fabs(x) < 0x1p-13) {
         const double x2 = x * x;
         return fma(x * x2, fma(x2, 3.0 / 40.0, 1.0 / 6.0), x);
     }
-    return asin(x);
+    return lib_asin(x);
 }
 
 // cos(x) for the latitudes of a southern cap: x in (-3 pi/4, -pi/4) and not within 2^-20 of -pi/2.  cos x = sin(x + pi/2): the 33-bit head
@@ -151,7 +157,7 @@ OGG_DEV double cos_cap(double x) {
     constexpr double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
     const double z = x + pio2_1;
     const bool in_range = (x < -0.7853981633974483) && (x > -2.356194490192345) && (fabs(z) >= 0x1p-20);
-    if (__builtin_expect(__ballot(!in_range) != 0ull, 0)) return cos(x);
+    if (__builtin_expect(__ballot(!in_range) != 0ull, 0)) return lib_cos(x);
     const double y0 = z + pio2_1t;
     const double y1 = (z - y0) + pio2_1t;
     constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
@@ -449,6 +455,9 @@ OGG_DEV void dq_probe_pair(int k, const double* r, const cplx* ep, double& ra, d
     }
 }
 
+#ifndef OGG_DQ_PIPELINE
+#define OGG_DQ_PIPELINE 1   // literal form: one-row software pipeline of the look-back (0: finish a row right after its evaluation)
+#endif
 #ifndef OGG_DQ_UNROLL
 #define OGG_DQ_UNROLL 8   // the probe loop fully unrolled (no compare-selects to pick a probe's operands and result slots): 233 VGPRs
 #endif                    // like the rolled loop's 238, 2.0 -> 1.67 ms for config 4; 1 = rolled
@@ -567,8 +576,12 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
 #pragma unroll
     for (int k = 0; k < F; ++k) pend.va[k] = pend.vb[k] = pend.pa[k] = pend.pb[k] = 0.0;
     pend_next = pend;
+    // PIPE: row L + 1 is evaluated between publishing row L's maps and reading its predecessors' (the wait is hidden, the pending state
+    // of two rows lives in registers); !PIPE: a row is finished right after its evaluation (half the pending state: one wave more per SIMD
+    // for the literal form at order 4, which then has to hide the wait)
+    constexpr bool PIPE = (OGG_DQ_PIPELINE != 0) || (ARC == DP_ARC_CHORD);
 #pragma unroll 1
-    for (long L = -1; L < n_lat; ++L) {
+    for (long L = -1; L < (PIPE ? n_lat : n_lat - 1); ++L) {
         // ---- evaluate lattice row L + 1 ------------------------------------------------------------------------------
         if (L + 1 < n_lat) {
             const long row = M * r0 + L + 1;      // band-local lattice row
@@ -608,17 +621,22 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
                 if (lane == 63) lb_publish(words + (L + 1) * p.n_strips + strip, f0, f1);
             }
         }
-        // ---- finish lattice row L and feed it to the quadrature ---------------------------------------------------------
-        if (L >= 0) {
+        if (!PIPE) {
+            pend = pend_next;
+            inc0 = inc0_next, inc1 = inc1_next;
+        }
+        // ---- finish lattice row Lf and feed it to the quadrature --------------------------------------------------------
+        const long Lf = PIPE ? L : L + 1;
+        if (Lf >= 0) {
             double hi, hj;
             if (ARC == DP_ARC_CHORD) {
                 hi = chi, hj = chj;
             } else {
-                const unsigned s_in = (strip > 0) ? lb_incoming(words + L * p.n_strips, strip, ALL, (int*)(p.ticket + 1)) : 0u;
+                const unsigned s_in = (strip > 0) ? lb_incoming(words + Lf * p.n_strips, strip, ALL, (int*)(p.ticket + 1)) : 0u;
                 dq_literal_finish<F>(pend, map_apply(inc0, inc1, s_in), reps, hi, hj);
             }
-            const long k = L / M;                 // cell row of the chunk this lattice row is the row jj of
-            const int jj = (int)(L % M);
+            const long k = Lf / M;                // cell row of the chunk this lattice row is the row jj of
+            const int jj = (int)(Lf % M);
             const double pr = hi * hj;            // OGG:589
             double ah[N], ap[N];                  // h_i and h_i h_j at this column and its M right-hand neighbours
             ah[0] = hi, ap[0] = pr;
@@ -653,8 +671,10 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
                 p.dxq[(r0 + nc) * p.g.ni + ci] = qavg_1d<N>(ah) * p.Re;
             }
         }
-        pend = pend_next;
-        inc0 = inc0_next, inc1 = inc1_next;
+        if (PIPE) {
+            pend = pend_next;
+            inc0 = inc0_next, inc1 = inc1_next;
+        }
         chi = pend_next.va[0], chj = pend_next.vb[0];
     }
 }

@@ -15,7 +15,7 @@ ap.add_argument("--libs", nargs="+", required=True)
 ap.add_argument("--workloads", nargs="+", default=["r8"])
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=200)
-ap.add_argument("--extra", nargs="*", default=[])
+ap.add_argument("--extra", default="", help="more bench.py arguments, one string (e.g. --extra=\"--dp-arc literal\")")
 ap.add_argument("--json", default=None)
 args = ap.parse_args()
 res = {}
@@ -23,7 +23,7 @@ for rnd in range(args.rounds):
     for wl in args.workloads:
         for lib in args.libs:
             env = dict(os.environ, OGG_LIB_PATH=os.path.abspath(lib))
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(args.steps), "--cpu-sample-div", "0", "--d2h", "0", "--checksum", "0", "--power-probe", "0"] + args.extra,
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(args.steps), "--cpu-sample-div", "0", "--d2h", "0", "--checksum", "0", "--power-probe", "0"] + args.extra.split(),
                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if out.returncode:
                 print(out.stderr[-2000:], flush=True)
