@@ -15,8 +15,12 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
             a = asin_unit(x[k]), b = asin(x[k]);
         else if (which == 1)
             a = atan_lib(x[k]), b = atan(x[k]);
-        else
+        else if (which == 2)
             a = atan2_lib(y[k], x[k]), b = atan2(y[k], x[k]);
+        else if (which == 3)
+            a = rcp_ieee_normal(x[k]), b = 1.0 / x[k];
+        else
+            a = sqrt_ieee_normal(x[k]), b = sqrt(x[k]);
         diff = __double_as_longlong(a) != __double_as_longlong(b);
     }
     const unsigned long long m = __ballot(diff);
@@ -27,7 +31,7 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
 extern "C" {
 
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream) {
-    OGG_REQUIRE(which >= 0 && which <= 2 && n >= 0 && x && n_diff && (which != 2 || y), OGG_EARG, "ogg_libm_check: bad argument");
+    OGG_REQUIRE(which >= 0 && which <= 4 && n >= 0 && x && n_diff && (which != 2 || y), OGG_EARG, "ogg_libm_check: bad argument");
     if (n == 0) return OGG_OK;
     libm_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(which, n, x, y, n_diff);
     OGG_LAUNCH_CHECK();

@@ -192,8 +192,8 @@ OGG_DEV double asin_unit(double x) {
 }
 
 // lams of OGG:50-64
-OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double rden, double lamg, double lon_bp) {
-    double B = c.sinla * sqrt(rden);
+OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double sqrt_rden, double lamg, double lon_bp) {   // sqrt_rden: sqrt(rden), IEEE
+    double B = c.sinla * sqrt_rden;
     if (fabs(r.beta2_inv) > kHuge) B = 0.0;
     double lamc = div_pi180(asin_unit(B));   // B in [0, 1]
     const double dl = lamg - lon_bp;
@@ -216,7 +216,7 @@ __global__ void bipolar_projection_kernel(long n, const double* __restrict__ lam
     const BpCol c = bp_col(lg, lon_bp);
     double ps, h_i, h_j, rden;
     bp_point(r, c, rp, ps, h_i, h_j, rden);
-    if (lams) lams[k] = bp_lams(r, c, rden, lg, lon_bp);
+    if (lams) lams[k] = bp_lams(r, c, sqrt(rden), lg, lon_bp);
     if (phis) phis[k] = ps;
     if (hi) hi[k] = h_i;
     if (hj) hj[k] = h_j;
@@ -314,8 +314,10 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
     for (int r = 0; r < nr; ++r) {
         const BpRow row = s_row[r];
         const long jl = jl0 + r, j = j0 + jl;
-        const double rden = 1.0 / (1.0 + c.alpha2 * row.beta2_inv);                    // OGG:47
-        const double lam = bp_lams(row, c, rden, lamg, lon_bp);
+        // OGG:47, and the square root of OGG:50: IEEE division and root -- the same bits -- without the scaling and special-case steps
+        // that 1 <= 1 + a b <= 1e33 does not need (a in [0, 1]; b = tan^2 of a latitude that is at most 90 degrees ROUNDED: <= 2.7e32)
+        const double rden = rcp_ieee_normal(1.0 + c.alpha2 * row.beta2_inv);
+        const double lam = bp_lams(row, c, sqrt_ieee_normal(rden), lamg, lon_bp);
         const double A = c.sinla * row.sphig;
         const double m1 = 1 - A, p1 = 1 + A;
         const double t = (m1 > 0.0) ? m1 * rsqrt_c3(m1 * p1) : 0.0;                    // sqrt((1-A)/(1+A)) == tan(acos(A)/2), OGG:69-70

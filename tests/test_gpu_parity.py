@@ -277,6 +277,24 @@ def test_atan_atan2_restatements_equal_the_library(hip):
     assert _libm_check(2, x, y) == 0
 
 
+def test_rcp_and_sqrt_without_scaling_equal_the_ieee_operations(hip):
+    """rcp_ieee_normal / sqrt_ieee_normal (ogg_math.h: the compiler's own fma sequences without the scaling and special-case steps) against
+    1.0 / x and sqrt(x): every bit, 4e7 operands over 2^-700 .. 2^700 incl. powers of two and their neighbours."""
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(13)
+    n = 40_000_000
+    m = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) + 1.0
+    m[: n // 16] = 1.0 + torch.randint(0, 64, (n // 16,), device="cuda:0", generator=g).to(torch.float64) * 2.0 ** -52      # just above 2^k
+    m[n // 16: n // 8] = 2.0 - (1 + torch.randint(0, 64, (n // 16,), device="cuda:0", generator=g).to(torch.float64)) * 2.0 ** -52
+    e = torch.randint(-700, 700, (n,), device="cuda:0", generator=g).to(torch.float64)
+    x = torch.ldexp(m, e.to(torch.int32))
+    x[n // 2:] = 1.0 + torch.rand(n - n // 2, dtype=torch.float64, device="cuda:0", generator=g) * 1e6      # the mesh's 1 + a b
+    x[-4:] = torch.tensor([1.0, 2.0 ** -700, 2.0 ** 700, 4.0], dtype=torch.float64, device="cuda:0")
+    assert _libm_check(3, x) == 0
+    x[n // 2:] = 1.0 / x[n // 2:]                                                                          # the mesh's rden
+    assert _libm_check(4, x) == 0
+
+
 def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
     got = []
     for rows in ("8", "1", "5", "32"):
