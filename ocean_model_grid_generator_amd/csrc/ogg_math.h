@@ -56,6 +56,28 @@ OGG_DEV double mdist(double x1, double x2) {
     return fmin(pymod360(x1 - x2), pymod360(x2 - x1));
 }
 
+// IEEE 1/x and sqrt(x) -- correctly rounded, the SAME bits as the compiler's expansions of `1.0 / x` and `sqrt(x)` -- for operands
+// that need none of the scaling and special-case handling those expansions carry (2^-700 <= x <= 2^700): the same seed and the same
+// fma steps, without v_div_scale / v_div_fmas / v_div_fixup (7 instead of 11 instructions) and without the range test, the two
+// ldexp and the zero / infinity selects of the square root (10 instead of 21).  Bit-identity is a test (ogg_libm_check_dev, 4e7
+// operands each).  Used where the reference divides or takes a root of a quantity whose range is known (the cap mesh: 1 + a b in
+// [1, 1e30], its reciprocal in [1e-30, 1]).
+OGG_DEV double rcp_ieee_normal(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+
+OGG_DEV double sqrt_ieee_normal(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g), h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return fma(fma(-g, g, x), h, g);
+}
+
 struct cplx {
     double re, im;
 };
@@ -91,7 +113,7 @@ OGG_DEV double cabs_np(cplx w) {
     const double a = fmax(ar, ai), b = fmin(ar, ai);
     if (a == 0.0) return 0.0;
     const double r = b / a;
-    return a * sqrt(fma(r, r, 1.0));
+    return a * sqrt_ieee_normal(fma(r, r, 1.0));   // the argument lies in [1, 2]: IEEE sqrt, the same bits, without its scaling / special cases
 }
 
 // 1/x and 1/sqrt(x) for NORMAL, positive x from the hardware seed (v_rcp_f64 / v_rsq_f64, relative error e <= 2^-24 measured,
@@ -110,28 +132,6 @@ OGG_DEV double rsqrt_c3(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-(x * y), y, 1.0);
     return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-
-// IEEE 1/x and sqrt(x) -- correctly rounded, the SAME bits as the compiler's expansions of `1.0 / x` and `sqrt(x)` -- for operands
-// that need none of the scaling and special-case handling those expansions carry (2^-700 <= x <= 2^700): the same seed and the same
-// fma steps, without v_div_scale / v_div_fmas / v_div_fixup (7 instead of 11 instructions) and without the range test, the two
-// ldexp and the zero / infinity selects of the square root (10 instead of 21).  Bit-identity is a test (ogg_libm_check_dev, 4e7
-// operands each).  Used where the reference divides or takes a root of a quantity whose range is known (the cap mesh: 1 + a b in
-// [1, 1e30], its reciprocal in [1e-30, 1]).
-OGG_DEV double rcp_ieee_normal(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return fma(fma(-x, y, 1.0), y, y);
-}
-
-OGG_DEV double sqrt_ieee_normal(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g), h = fma(h, r, h);
-    g = fma(fma(-g, g, x), h, g);
-    return fma(fma(-g, g, x), h, g);
 }
 
 // Polynomial coefficients as SCALAR operands.  A 64-bit literal cannot be an operand of a gfx9 VALU instruction: the compiler
