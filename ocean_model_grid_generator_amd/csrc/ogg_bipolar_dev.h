@@ -613,7 +613,7 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         double ysum = 0.0;
 #pragma unroll
         for (int k = 0; k < N; ++k) dyc[k] = 0.0;
-#pragma unroll((N <= 3 || MODE == QM_FAST) ? N : 1)
+#pragma unroll((N <= 3 || MODE != QM_LITERAL) ? N : 1)
         for (int jj = 0; jj < N; ++jj) {
             if (jj > 0) {
                 // the top row of this cell row is the bottom row of the next one.  Every cell-edge lattice row is evaluated in the
