@@ -61,7 +61,7 @@ OGG_DEV double mdist(double x1, double x2) {
 // fma steps, without v_div_scale / v_div_fmas / v_div_fixup (7 instead of 11 instructions) and without the range test, the two
 // ldexp and the zero / infinity selects of the square root (10 instead of 21).  Bit-identity is a test (ogg_libm_check_dev, 4e7
 // operands each).  Used where the reference divides or takes a root of a quantity whose range is known (the cap mesh: 1 + a b in
-// [1, 1e30], its reciprocal in [1e-30, 1]).
+// [1, 1e33], its reciprocal in [1e-33, 1]; numpy's complex absolute: 1 + r^2 in [1, 2]).
 OGG_DEV double rcp_ieee_normal(double x) {
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
