@@ -29,10 +29,10 @@ for rnd in range(args.rounds):
                 print(out.stderr[-2000:], flush=True)
                 raise SystemExit(1)
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            res.setdefault((wl, lib), []).append((d["ms_per_step"], d["pass_launches"].get("pass_b", {}).get("ms")))
+            res.setdefault((wl, lib), []).append((d["ms_per_step"], (d["pass_launches"] or {}).get("pass_b", {}).get("ms")))
             kern = {k: round(v["mean_ms"], 4) for k, v in (d.get("kernels") or {}).items()}
             res.setdefault((wl, lib, "kernels"), []).append(kern)
-            print(rnd, wl, os.path.basename(lib), "%.4f" % d["ms_per_step"], d["pass_launches"].get("pass_b", {}).get("ms"), kern, flush=True)
+            print(rnd, wl, os.path.basename(lib), "%.4f" % d["ms_per_step"], (d["pass_launches"] or {}).get("pass_b", {}).get("ms"), kern, flush=True)
 summary = {"%s|%s" % k: {"ms_per_step": [a for a, _ in v], "pass_b_ms": [b for _, b in v], "best_ms_per_step": min(a for a, _ in v),
                              "stand_alone_kernels_ms": res[k + ("kernels",)]} for k, v in res.items() if len(k) == 2}
 print(json.dumps(summary))
