@@ -377,6 +377,8 @@ struct QuadParams {
     long j0;           // first cell row of the band (band-local output row 0)
     long top_out_row;  // band-local row of dxq that holds the j = ny row (the band that owns it), else -1
     double guard_k;       // exactness guard of bp_point_fast
+    unsigned* ll_claims;  // QUAD_LL_CLAIM_WORDS words behind the fix-up counter: claim counters of the lat-lon strips of a fused pass
+                          // (ogg_latlon_fused_dev.h), zeroed with the tables
     unsigned* fix_count;  // number of cells handed to the literal fix-up ...
     unsigned* fix_list;   // ... and their band-local linear indices out_r*nx + ci
     const BpRow* row_tab;  // [(N-1)*ny + 2]: unique lattice rows; entry (N-1)*ny is the ny-0.001 row, the last one is j = ny exactly
@@ -413,6 +415,8 @@ OGG_DEV double quad_weight_1d(int k) {  // w[k] of OGG:240 / 248, as selects (k 
     if (N == 4) return (k == 0 || k == 3) ? 1.0 : 5.0;
     return (k == 0 || k == 4) ? 9.0 : ((k == 2) ? 64.0 : 49.0);
 }
+
+constexpr int QUAD_LL_CLAIM_WORDS = 2048;   // 2 per lat-lon workgroup of a pass: up to 1024 resident workgroups
 
 template <int N>
 __host__ __device__ inline unsigned tables_only_blocks(const QuadParams& p) {
@@ -471,6 +475,7 @@ OGG_DEV void bipolar_tables_body(const QuadParams& p, long bx) {
     const long k = bx * blockDim.x + threadIdx.x;
     const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
     if (k == 0) *p.fix_count = 0u;  // the fix-up list of this call starts empty (this kernel precedes the quadrature kernels)
+    for (long w = k; w < QUAD_LL_CLAIM_WORDS; w += nb_tab * blockDim.x) p.ll_claims[w] = 0u;   // (and nothing of the pass is claimed)
     if (k < n_rows) {
         double jv;
         if (k == M * p.ny)
@@ -781,7 +786,7 @@ template <int N>
 size_t quad_workspace_bytes(long nx, long ny, long n_cell_rows) {
     constexpr int M = N - 1;
     const size_t tabs = (size_t)(M * ny + 2) * sizeof(BpRow) + (size_t)(M * nx + 1) * sizeof(BpCol);
-    return tabs + 16 + (size_t)(n_cell_rows > 0 ? n_cell_rows : 0) * nx * sizeof(unsigned);
+    return tabs + 16 + QUAD_LL_CLAIM_WORDS * sizeof(unsigned) + (size_t)(n_cell_rows > 0 ? n_cell_rows : 0) * nx * sizeof(unsigned);
 }
 
 // Launch plan of one quadrature call: which cell rows run the plain algebraic form, which carry the guard, whether the
@@ -805,7 +810,8 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     p.row_tab = row_tab;
     p.col_tab = col_tab;
     p.fix_count = fix_count;
-    p.fix_list = fix_count + 4;
+    p.ll_claims = fix_count + 4;
+    p.fix_list = fix_count + 4 + QUAD_LL_CLAIM_WORDS;
     p.guard_k = guard_k;
     p.top_out_row = (n_dx_rows > n_cell_rows) ? n_cell_rows : -1;
     const double rp2 = p.rp * p.rp;

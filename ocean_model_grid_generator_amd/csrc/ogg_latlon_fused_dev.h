@@ -156,8 +156,17 @@ inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
 // the 8 XCDs round-robin, so workgroup b runs on XCD b % 8; the remap below gives every XCD a CONTIGUOUS eighth of the row
 // strips (all column tiles of those rows) and every workgroup a contiguous block of strips, instead of interleaving the XCDs
 // strip by strip: +15 % on the write plateau in scripts/microbench/write_patterns.hip (pattern b2).
+//
+// claims (NULL: none): two 32-bit counters per (column tile, row block), zero at the start of the launch.  With them the block's strips
+// are CLAIMED one at a time -- counter 0 counts claims, a claim beyond the block's strip count ends the walk -- by the block's resident
+// workgroup, which takes its k-th claim at strip s_first + k (the same ascending walk as without claims), and by HELPER workgroups
+// (helper = true; counter 1 numbers their claims), which take theirs from the far end, s_last - 1 - j: the two sets cannot meet before
+// the claims run out.  Helpers sit at the END of a fused launch, so they start when the compute workgroups drain: if the strips are
+// what is left by then (1/16 degree on a box with a slow write path: 300 us of a 1.2 ms launch with nothing but the 90 resident
+// workgroups running) the whole chip finishes them; if not, they find nothing to claim and leave.  s_claim: one LDS word.
 template <bool NT>
-OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi) {
+OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi,
+                               unsigned* claims = nullptr, bool helper = false, int* s_claim = nullptr) {
     const long v = xcd_contiguous(b, gx * gy);   // virtual index: the workgroups of XCD x are consecutive
     const long bx = v % gx, by = v / gx;
     const int tid = threadIdx.x;
@@ -169,7 +178,24 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
     // VALU-bound workgroups can share the CUs; each workgroup walks its block of row strips.
     const long per = (strip_hi - strip_lo + gy - 1) / gy;
     const long s_first = strip_lo + by * per, s_last = (s_first + per < strip_hi) ? s_first + per : strip_hi;
-    for (long strip = s_first; strip < s_last; ++strip) {
+    unsigned* cnt = claims ? claims + 2 * (by * gx + bx) : nullptr;
+    long walked = 0;   // strips this workgroup has taken (wave-uniform)
+    for (long strip = s_first;; ++strip) {
+        if (cnt) {
+            if (tid == 0) {
+                const unsigned n = (unsigned)(s_last > s_first ? s_last - s_first : 0);
+                int pick = -1;
+                if (atomicAdd(cnt, 1u) < n) pick = helper ? (int)(n - 1u - atomicAdd(cnt + 1, 1u)) : (int)walked;
+                *s_claim = pick;
+            }
+            __syncthreads();
+            const int pick = *s_claim;   // (the barriers of the strip's body separate this read from the next write)
+            if (pick < 0) break;
+            strip = s_first + pick;
+            ++walked;
+        } else if (strip >= s_last) {
+            break;
+        }
         int bi = 0;
         while (bi + 1 < p.n_bands && strip >= p.strip0[bi + 1]) ++bi;
         const ogg_latlon_band& b = p.band[bi];

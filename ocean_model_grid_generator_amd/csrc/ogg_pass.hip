@@ -37,6 +37,9 @@ struct LatlonShare {
     long gx, gy;
     long strip_lo, strip_hi;
     int nt;         // non-temporal stores (ogg_latlon_fused_dev.h, store2): when the strips share the launch with cap workgroups
+    unsigned* claims;   // claim counters of the strips (2 per resident workgroup; zeroed by launch A), or NULL: every workgroup its block
+    long n_help;        // helper workgroups at the END of the launch (claims != NULL): n_wg * OGG_PASS_LL_HELPERS
+    long points;        // lat-lon points of the strips (host side: size class of the launch)
 };
 
 union PassLds {
@@ -115,12 +118,21 @@ template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ PassLds lds;
     __shared__ unsigned s_slot;
+    __shared__ int s_claim;
     long b = blockIdx.x;
-    if (b < a.share.n_wg) {
+    const long first_help = (long)gridDim.x - a.share.n_help;
+    const bool helper = b >= first_help;
+    if (b < a.share.n_wg || helper) {
+        if (helper) {
+            // helper k of the launch takes the block of a resident workgroup on ITS XCD (workgroup b runs on XCD b % 8)
+            const long k = b - first_help, n = a.share.n_wg;
+            long r = (k / 8) * 8 + (b % 8);
+            b = r % n;
+        }
         if (a.share.nt)
-            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim);
         else
-            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi);
+            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim);
         return;
     }
     b -= a.share.n_wg;
@@ -178,6 +190,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // resident lat-lon workgroups: enough to keep the HBM write path busy and not more, so that the VALU-bound workgroups of
     // the same launch get the remaining wave slots; a launch without compute workgroups takes the whole chip
     const long points = (hi - lo) * ll.rows_per_block * ni1;
+    s.points = points;
     // measured optima (1/8 degree, shares 1, 1/2, 1/4, 1/8 = 19.8, 9.9, 5, 2.5 M points): 60, 90, 90-120, 120 -- the smaller the share,
     // the shorter the VALU work the strips can hide behind, so they need more of the write bandwidth
     long max_wg = alone ? 2048
@@ -314,7 +327,16 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         for (int k = 0; k < N_ROLES; ++k)
             B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : dflt[k];
         B.share = make_share(ll, s1, n_strips_ll, ni1, false);
-        const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad);
+        // helper workgroups for the lat-lon strips at the end of the launch (ogg_latlon_fused_dev.h): the claim counters live in the
+        // bipolar cap's workspace and are zeroed by launch A with its tables
+        // (measured: 1/8 degree whole grid 0.246 -> 0.237 ms, 1/16 degree 1.23 -> 1.19; half, a quarter, an eighth of the 1/8 degree grid
+        // +1 %, +1 %, +4 %: the claims cost more than a tail that short gives back -- whole-grid launches only)
+        const long helpers = env_long("OGG_PASS_LL_HELPERS", B.share.points >= 16000000 ? 2 : 0);
+        if (have_quad && helpers > 0 && B.share.n_wg > 0 && 2 * B.share.n_wg <= QUAD_LL_CLAIM_WORDS) {
+            B.share.claims = qp.p.ll_claims;
+            B.share.n_help = B.share.n_wg * helpers;
+        }
+        const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad + B.share.n_help);
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
         OGG_LAUNCH_CHECK();
     }

@@ -22,11 +22,12 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--set", nargs="*", default=[])
 ap.add_argument("--as-rank", type=int, default=0)
 ap.add_argument("--as-world", type=int, default=1)
+ap.add_argument("--dp-arc", default="chord")
 args = ap.parse_args()
 for kv in args.set:
     k, v = kv.split("=", 1)
     os.environ[k] = v
-plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
+plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **bench.WORKLOADS[args.workload])
 sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device="cuda:0", halo="recompute")
 sg.launch = "pass"
 for _ in range(60):

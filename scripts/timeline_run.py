@@ -1,0 +1,17 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch, bench
+from ocean_model_grid_generator_amd import supergrid
+for wl in sys.argv[1:]:
+    plan = supergrid.SupergridPlan(dp_arc="chord", **bench.WORKLOADS[wl])
+    sg = supergrid.Supergrid(plan, device="cuda:0")
+    sg.launch = "pass"
+    os.environ.pop("OGG_TIMELINE", None)
+    for _ in range(100): sg.run_pass()
+    torch.cuda.synchronize()
+    os.environ["OGG_TIMELINE"] = "1"
+    for _ in range(3):
+        print("==", wl, file=sys.stderr, flush=True)
+        sg.run_pass()
+    os.environ.pop("OGG_TIMELINE", None)
+    del sg
