@@ -114,15 +114,40 @@ struct PassBParams {
 // roles of launch B's workgroups; PassBParams::order lists them in dispatch order
 enum { ROLE_BP_MESH = 0, ROLE_DP_MESH, ROLE_BP_GUARD, ROLE_BP_FAST, ROLE_DP_QUAD, N_ROLES };
 
+#ifdef OGG_PASS_TIMELINE   // experiment build (scripts/ab_build.sh WORK tl -DOGG_PASS_TIMELINE=1; scripts/timeline_run.py): first start and
+// last end of every role of launch B in 10 ns ticks (s_memrealtime), printed by the host when OGG_TIMELINE is set
+__device__ unsigned long long g_tl_min[8], g_tl_max[8];
+struct TlScope {
+    int role;
+    __device__ TlScope() : role(7) {
+        if (threadIdx.x == 0) atomicMin(&g_tl_min[7], __builtin_amdgcn_s_memrealtime());
+    }
+    __device__ ~TlScope() {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&g_tl_max[role], __builtin_amdgcn_s_memrealtime());
+    }
+    __device__ void set(int r) {
+        role = r;
+        if (threadIdx.x == 0) atomicMin(&g_tl_min[r], __builtin_amdgcn_s_memrealtime());
+    }
+};
+#endif
+
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ PassLds lds;
     __shared__ unsigned s_slot;
     __shared__ int s_claim;
+#ifdef OGG_PASS_TIMELINE
+    TlScope tl;
+#endif
     long b = blockIdx.x;
     const long first_help = (long)gridDim.x - a.share.n_help;
     const bool helper = b >= first_help;
     if (b < a.share.n_wg || helper) {
+#ifdef OGG_PASS_TIMELINE
+        tl.set(helper ? 6 : 5);
+#endif
         if (helper) {
             // helper k of the launch takes the block of a resident workgroup on ITS XCD (workgroup b runs on XCD b % 8)
             const long k = b - first_help, n = a.share.n_wg;
@@ -148,6 +173,9 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
                 b -= n;
         }
     }
+#ifdef OGG_PASS_TIMELINE
+    if (role >= 0) tl.set(role);
+#endif
     if (role == ROLE_BP_MESH) {
         bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
     } else if (role == ROLE_DP_MESH) {   // work item from the ticket, not from the workgroup index: see ogg_dpole_dev.h
@@ -337,8 +365,27 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
             B.share.n_help = B.share.n_wg * helpers;
         }
         const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad + B.share.n_help);
+#ifdef OGG_PASS_TIMELINE
+        {
+            unsigned long long mn[8], mx[8];
+            for (int k = 0; k < 8; ++k) mn[k] = ~0ull, mx[k] = 0ull;
+            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_min), mn, sizeof(mn)));
+            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_max), mx, sizeof(mx)));
+        }
+#endif
         pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
         OGG_LAUNCH_CHECK();
+#ifdef OGG_PASS_TIMELINE
+        if (getenv("OGG_TIMELINE")) {
+            OGG_HIP_CHECK(hipStreamSynchronize(st));
+            unsigned long long mn[8], mx[8];
+            OGG_HIP_CHECK(hipMemcpyFromSymbol(mn, HIP_SYMBOL(g_tl_min), sizeof(mn)));
+            OGG_HIP_CHECK(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_tl_max), sizeof(mx)));
+            static const char* nm[8] = {"bp_mesh", "dp_mesh", "bp_guard", "bp_fast", "dp_quad", "latlon", "ll_help", "any"};
+            for (int k = 0; k < 8; ++k)
+                if (mx[k]) fprintf(stderr, "timeline %-8s first start %8.1f us  last end %8.1f us\n", nm[k], (double)(mn[k] - mn[7]) * 0.01, (double)(mx[k] - mn[7]) * 0.01);
+        }
+#endif
     }
     if (int e = mark(2)) return e;
     if (have_quad) {

@@ -1,3 +1,7 @@
+"""First start / last end of every role of launch B (needs an experiment build of the library):
+    scripts/ab_build.sh WORK tl -DOGG_PASS_TIMELINE=1
+    OGG_LIB_PATH=$PWD/ab/libogg_hip_tl.so python scripts/timeline_run.py r8 r16 r8_latdp
+"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench
