@@ -191,7 +191,8 @@ typedef struct ogg_bipolar_band {
     long n_cell_rows;        /* cell rows: dy (n_cell_rows x (Ni+1)), area (n_cell_rows x Ni); n_pt_rows - 1 on the band that
                                 holds row Nj, else n_pt_rows */
     double *x, *y, *angle, *dx, *dy, *area;
-    void* workspace;         /* >= ogg_bipolar_quad_workspace_bytes(order, Ni, Nj) bytes of device memory (metrics only) */
+    void* workspace;         /* >= ogg_bipolar_quad_workspace_bytes(order, Ni, Nj) bytes of device memory (metrics only): tables,
+                                fix-up list, claim counters of the lat-lon strips; one pass at a time per workspace */
     long workspace_bytes;
 } ogg_bipolar_band;
 int ogg_tripolar_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,
