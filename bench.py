@@ -5,8 +5,9 @@
 
 A step is one full pass of the hot path over the whole supergrid (all sub-grids: axes, coordinate tiles / meshes, halo
 exchange, MIDAS metrics + angle, cap quadratures), inputs being ~10 scalars, outputs (six fp64 fields) left in HBM.
-For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL); every sub-grid is split into N latitude bands and
-the total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+For N > 1 it runs one rank per GPU over RCCL: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+the environment), or by itself -- a plain `python bench.py --gpus N` starts the N ranks as child processes and relays rank 0's line.
+Every sub-grid is split into N latitude bands and the total work is fixed, so scaling is "strong".  ONE JSON line on stdout.
 
 Extra objects on that line:
   roofline      the kernel with the largest share of the step, priced as HBM traffic: algorithmic bytes per launch /
@@ -225,6 +226,45 @@ def power_probe(sg, torch, seconds, card_index=0):
     return out or None
 
 
+def self_launch_command(n, argv, port):
+    """The command `python bench.py --gpus N` runs for N > 1 when it was not started under torch.distributed.run: one rank per GPU
+    of this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, timeout=None):
+    """Run the N ranks as children of this process (which has not touched the GPU and never does), pass their stderr through, print
+    rank 0's ONE JSON line on stdout and return the exit code for this process: the children's if they failed, 1 if no line came."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = self_launch_command(n, argv, port)
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as exc:
+        sys.stderr.write("bench.py: the %d ranks did not finish within %s s\n" % (n, exc.timeout))
+        return 124
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():
+        if not l.startswith("{"):
+            sys.stderr.write(l + "\n")
+    if p.returncode != 0:
+        sys.stderr.write("bench.py: torch.distributed.run with %d ranks failed (exit code %d): %s\n" % (n, p.returncode, " ".join(cmd)))
+        return p.returncode
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        return 1
+    print(lines[-1])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,16 +295,18 @@ def main():
                          "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as CHILD processes, before anything here touches the GPU (no exec)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     use_dist = world > 1 or bool(os.environ.get("OGG_FORCE_DIST"))   # OGG_FORCE_DIST: exercise the RCCL calls at world size 1

@@ -1,8 +1,9 @@
 """Multi-GPU readiness: on a box with >= 2 visible GPUs, bench.py under torch.distributed.run with 2 ranks (RCCL) must reproduce
 the single-GPU result bit for bit -- for the default pipeline (fused pass, no data-path collective) and for the pipeline of
 BASELINE.json's north_star taken literally (tile, one-row halo over RCCL send/recv, generic stencil kernel).  Skips itself on a
-one-GPU box (the driver's 8-GPU node is the only place this runs for real).  The children are separate processes started from
-scratch (nothing is exec'ed from this process)."""
+one-GPU box (the driver's 8-GPU node is the only place this runs for real).  bench.py is invoked plainly (`python bench.py --gpus 2`): it
+starts its two ranks as child processes itself (tests/test_bench_launch.py covers that launcher on the CPU); a third case goes through
+torch.distributed.run explicitly, the way the driver launches N > 1."""
 import json
 import os
 import socket
@@ -28,15 +29,23 @@ def _port():
 
 def _bench(n, extra):
     args = ["bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1", "--cpu-sample-div", "0", "--d2h", "0", "--workload", "r2"] + extra
-    if n == 1:
-        cmd = [sys.executable] + args
-    else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-               "--master-port", str(_port())] + args
+    cmd = [sys.executable] + args   # the plain invocation: for n > 1 bench.py starts its ranks itself (child processes under torch.distributed.run)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_two_ranks_under_torchrun_as_the_driver_launches_them():
+    if _gpus() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-sample-div", "0", "--d2h", "0",
+           "--workload", "r2"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    two = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["world_size"] == 2 and two["field_checksums"] == _bench(1, [])["field_checksums"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--latlon", "stencil", "--halo", "rccl"]], ids=["fused_pass", "stencil_rccl_halo"])
