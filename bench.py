@@ -154,6 +154,45 @@ def _dp_parity(arc):
             "chord_vs_literal_max_rel": rec["full_size_chord_vs_literal_max_rel"]}
 
 
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4   # wave64 fp64 VALU instructions per ns over the chip: 1024 SIMDs, 2.4 GHz, 4 cycles per instruction
+
+
+def valu_bound_roofline(hbm_roof, valu, launch_ms):
+    """The roofline object of a launch that is fp64-VALU bound (its HBM fraction says nothing: a cap quadrature writes 24 B per cell behind
+    thousands of fp64 instructions): priced in wave64 VALU instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles.  The instruction
+    count per launch comes from the committed counters of the same kernel sources (`valu`); without them the HBM pricing stays, labelled."""
+    if not valu or not valu.get("wave64_valu_instr_per_launch"):
+        hbm_roof["limited_by"] = "fp64 VALU issue (no counters of this library's kernels under profiles/ to price it: HBM pricing kept)"
+        return hbm_roof
+    ach = valu["wave64_valu_instr_per_launch"] / (launch_ms * 1e-3) / 1e9
+    return {"kernel": hbm_roof["kernel"], "bound": "fp64 VALU", "achieved": round(ach, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave64-instr/s",
+            "frac": round(ach / VALU_PEAK_GINSTR, 4), "valu_busy_frac": valu.get("valu_busy_frac"), "traffic": hbm_roof.get("traffic"),
+            "hbm": {"achieved": hbm_roof["achieved"], "peak": hbm_roof["peak"], "unit": "GB/s", "frac": hbm_roof["frac"]},
+            "note": "the launch that takes the largest share of the step is fp64-VALU bound: wave64 VALU instructions per launch (committed "
+                    "counters of the same kernel sources) / this run's launch duration, against 1024 SIMDs x 2.4 GHz / 4 cycles per fp64 "
+                    "instruction; `valu_busy_frac` = SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the counter run; `hbm` = the same launch "
+                    "priced in algorithmic bytes (24 B per cell: meaningless as a bound here, kept because north_star asks for it)",
+            "source": valu.get("source")}
+
+
+def time_other_arc(supergrid, plan_flags, arc, device, steps, torch):
+    """ms per pass of the same workload with the OTHER arc form of the displaced-pole quadrature (a second set of band buffers; after the
+    timed region)."""
+    plan = supergrid.SupergridPlan(dp_arc=arc, **plan_flags)
+    sg = supergrid.Supergrid(plan, rank=0, world=1, device=device, halo="recompute")
+    sg.launch, sg.overlap = "pass", False
+    for _ in range(30):
+        sg.run_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sg.run_pass()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"dp_arc": arc, "ms_per_step": ms, "value": plan.cells / (ms * 1e-3), "unit": "cells/s", "launch": "pass, eager", "steps": steps,
+            "note": "same workload, the other arc form (opt-in for chord: OGG_DP_ARC / dp_arc / arc_form); not part of `value`"}
+
+
 def power_probe(sg, torch, seconds, card_index=0):
     """Socket power and clocks (rocm-smi) while (a) the fused pass, (b) the stand-alone lat-lon kernel, (c) the stand-alone cap kernels run
     in a loop for `seconds` each, after the timed region.  The fused pass of the headline workload draws the socket's power limit
@@ -286,10 +325,13 @@ def main():
     ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
     ap.add_argument("--power-probe", type=float, default=1.5, help="after the timed region (1 GPU): seconds per phase of the rocm-smi power / "
                     "clock probe (fused pass, lat-lon kernel alone, cap kernels alone); 0: skip")
-    ap.add_argument("--dp-arc", default="chord", choices=["chord", "literal"],
-                    help="arc form of the displaced-pole quadrature (workloads with a displaced pole only): chord (same finite-difference "
-                         "stencil, distances from the probes' positions on the sphere) or literal (the reference's haversine arithmetic); "
-                         "both are ~1.3e-9 relative from the CPU oracle at 1/8 degree (see `parity` on the output line)")
+    ap.add_argument("--dp-arc", default="literal", choices=["chord", "literal"],
+                    help="arc form of the displaced-pole quadrature that `value` / `ms_per_step` are measured on (workloads with a displaced pole "
+                         "only): literal (default: the reference's haversine arithmetic, what main() and every entry point run unless told "
+                         "otherwise) or chord (opt-in: same finite-difference stencil, distances from the probes' positions on the sphere); "
+                         "both are ~1.3e-9 relative from the CPU oracle at 1/8 degree (`parity`).  The other form is timed after the timed "
+                         "region and reported as `dp_arc_other` (--dp-arc-other 0: skip)")
+    ap.add_argument("--dp-arc-other", type=int, default=1)
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
                     help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
                          "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
@@ -449,6 +491,12 @@ def main():
             del pinned
         except Exception as exc:
             d2h = {"error": repr(exc)}
+    dp_other = None
+    if has_dp and args.dp_arc_other and world == 1 and args.as_rank is None and args.latlon == "fused":
+        try:
+            dp_other = time_other_arc(supergrid, flags, "chord" if args.dp_arc == "literal" else "literal", device, args.steps, torch)
+        except Exception as exc:  # never lose the bench line over the secondary number
+            dp_other = {"error": repr(exc)}
     power = None
     if args.power_probe > 0 and world == 1 and args.latlon == "fused" and args.as_rank is None:
         try:
@@ -480,11 +528,20 @@ def main():
             kernels[k] = {"launches_per_step": launches_per_step, "mean_ms": round(v["mean_ms"], 5),
                           "ms_per_step": round(v["total_ms"] / args.steps, 5), "alg_bytes_per_launch": int(alg_bytes),
                           "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        pmc = json.load(open(tfile)).get(args.workload, {}) if os.path.exists(tfile) else {}
-        vfile = os.path.join(ROOT, "profiles", "valu_counters.json")
-        vkey = args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else "")
-        valu = json.load(open(vfile)).get(vkey, {}) if os.path.exists(vfile) else {}
+        # counters kept under profiles/ (builder-side rocprofv3 --pmc runs of this command): quoted only when they were taken with a
+        # library built from the SAME kernel sources as the one loaded now (ogg_version() carries the source hash)
+        lib_hash = _lib.source_hash()
+        counters_note = {"lib_src_hash": lib_hash}
+
+        def committed(fname, key):
+            path = os.path.join(ROOT, "profiles", fname)
+            rec = json.load(open(path)).get(key, {}) if os.path.exists(path) else {}
+            h = rec.get("_lib_src_hash") if isinstance(rec, dict) else None
+            counters_note[fname] = {"key": key, "collected_with_src_hash": h, "quoted": bool(rec) and h == lib_hash}
+            return rec if (rec and h == lib_hash) else {}
+
+        pmc = committed("hbm_traffic.json", args.workload + (" --dp-arc chord" if (has_dp and args.dp_arc == "chord") else ""))
+        valu = committed("valu_counters.json", args.workload + (" --dp-arc chord" if (has_dp and args.dp_arc == "chord") else ""))
         roof_valu = None
         if launches:  # the launches of the fused pass, timed inside the timed region
             n_sampled = launches.pop("sampled_passes")
@@ -501,7 +558,8 @@ def main():
             roof = {"kernel": kname, "bound": "hbm", "achieved": launches[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": launches[dom]["hbm_frac"], "traffic": pmc.get(dom),
                     "traffic_source": "profiles/hbm_traffic.json: FETCH_SIZE / WRITE_SIZE passes of a builder-side rocprofv3 run of this command "
-                                      "(read side x2), committed -- not counters of this process",
+                                      "(read side x2), committed -- not counters of this process; null when those counters were taken with "
+                                      "other kernel sources than the loaded library's (`counters`)",
                     "limited_by": "fp64 VALU issue, not HBM (see roofline_valu)" if (vc and vc["valu_busy_frac"] > 0.6) else None,
                     "note": "longest of the launches of the fused pass; HIP events recorded by the library on the launch stream in "
                             "%d passes of the timed region.  It carries lat-lon row strips (HBM-write bound) AND cap mesh / quadrature "
@@ -519,6 +577,8 @@ def main():
                              "source": "profiles/valu_counters.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE of a builder-side "
                                        "rocprofv3 --pmc run of this command, committed -- not counters of this process; launch_ms is this "
                                        "run's own event time"}
+            if roof["frac"] < 0.25:
+                roof = valu_bound_roofline(roof, roof_valu, launches[dom]["ms"])
         else:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
             per_step = pmc.get(dom)  # PMC bytes per step of that kernel
@@ -528,6 +588,15 @@ def main():
                     "traffic_source": "profiles/hbm_traffic.json (builder-side rocprofv3 run, committed)",
                     "note": "per-kernel durations from the sequential events pass; latlon_fused (78 % of the cells) is the HBM-bound "
                             "kernel, the cap kernels are fp64-VALU bound (DESIGN.md 4)"}
+            if roof["frac"] < 0.25:   # e.g. the literal displaced-pole quadrature: 24 B per cell behind ~35 k fp64 instructions
+                kn = {"dpole_quad": "dpole_quad_kernel<4, 0>", "bipolar_quad": "bipolar_quad_kernel<5, 0>", "bipolar_mesh": "bipolar_mesh_kernel<false>",
+                      "dpole_mesh": "dpole_mesh_kernel"}.get(dom)
+                vc = valu.get(kn) if kn else None
+                rv = None
+                if vc:
+                    rv = {"kernel": kn, "valu_busy_frac": round(vc["valu_busy_frac"], 4), "wave64_valu_instr_per_launch": vc["wave64_valu_instr"],
+                          "source": "profiles/valu_counters.json (builder-side rocprofv3 --pmc run, committed; same kernel sources as the loaded library)"}
+                roof = valu_bound_roofline(roof, rv, kernels[dom]["mean_ms"])
         out = {
             "metric": METRIC, "value": plan.cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -540,7 +609,9 @@ def main():
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": roof, "roofline_valu": roof_valu, "pass_launches": launches,
+            "counters": counters_note,
             "parity": _dp_parity(args.dp_arc) if has_dp else None,
+            "dp_arc_other": dp_other,
             "self_check_metrics_error_percent": self_check, "field_checksums": checksums,
             "d2h_pinned_after_pass": d2h,
             "kernels": kernels,

@@ -32,6 +32,8 @@ extern "C" {
 #define OGG_DP_ARC_CHORD 1
 
 const char* ogg_last_error(void);
+/* "ogg_hip <version> (gfx950) src <hash>": <hash> = first 12 hex digits of the sha256 over the kernel sources the library was built
+ * from (csrc/build.py source_hash()); profiles/valu_counters.json and hbm_traffic.json record the hash they were collected with */
 const char* ogg_version(void);
 /* sizeof(ogg_latlon_band) for which = 0, sizeof(ogg_bipolar_band) for which = 1, sizeof(ogg_dpole_band) for which = 2 (-1
  * otherwise): lets a binding verify its layout */

@@ -216,6 +216,12 @@ def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def source_hash():
+    """The kernel-source hash compiled into the loaded library (the tail of ogg_version())."""
+    v = load().ogg_version().decode()
+    return v.split(" src ")[1] if " src " in v else None
+
+
 def device_count():
     n = c_int(0)
     rc = load().ogg_device_count(ctypes.byref(n))

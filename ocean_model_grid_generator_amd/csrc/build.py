@@ -17,6 +17,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-function"]
 
 
+def source_hash():
+    """First 12 hex digits of the sha256 over the kernel sources and headers, in a fixed order: compiled into the library
+    (ogg_version()) and recorded next to every counter file under profiles/, so that bench.py never quotes counters of other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        path = os.path.join(HERE, f)
+        if os.path.exists(path):
+            h.update(f.encode() + b"\0" + open(path, "rb").read() + b"\0")
+    return h.hexdigest()[:12]
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -29,13 +41,19 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS if os.path.exists(os.path.join(HERE, f))] + [__file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:   # a library built from other sources (a checkout that kept an old .so with fresh mtimes)
+        return source_hash().encode() not in open(LIB, "rb").read()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cc = hipcc()
+    src_hash = source_hash()
     objs = []
     procs = []
     for src in SOURCES:
@@ -43,7 +61,7 @@ def build(force=False, verbose=False):
         if not os.path.exists(path):
             continue
         obj = os.path.join(HERE, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [cc] + FLAGS + (['-DOGG_SRC_HASH="%s"' % src_hash] if src == "ogg_api.hip" else []) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -156,7 +156,12 @@ using ogg::DevScratch;
 extern "C" {
 
 const char* ogg_last_error(void) { return ogg::g_err; }
-const char* ogg_version(void) { return "ogg_hip 0.1 (gfx950)"; }
+#ifndef OGG_SRC_HASH
+#define OGG_SRC_HASH "unknown"
+#endif
+// "... src <hash>": the hash of the kernel sources this library was built from (csrc/build.py source_hash()); the counter files under
+// profiles/ carry the hash of the library they were taken with, and bench.py quotes them only when the two agree
+const char* ogg_version(void) { return "ogg_hip 0.3 (gfx950) src " OGG_SRC_HASH; }
 // sizeof of the descriptor structs of the ABI (0: ogg_latlon_band, 1: ogg_bipolar_band), so that a binding can check its layout
 long ogg_abi_sizeof(int which) {
     return which == 0 ? (long)sizeof(ogg_latlon_band)

@@ -17,10 +17,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--workload", default="r8")
 ap.add_argument("--cost", nargs="*", default=["1.3,1.3,50"])
-ap.add_argument("--dp-arc", default="chord")
+ap.add_argument("--dp-arc", default="literal")
 ap.add_argument("--json", default=None, help="append one JSON line per (world, cost) to this file")
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--launch", default="pass")
+ap.add_argument("--events", type=int, default=0, help="also print every rank's launch durations (HIP events around the launches of 20 extra passes)")
 args = ap.parse_args()
 for cost in args.cost:
     os.environ["OGG_BP_ROW_COST"] = cost
@@ -37,6 +38,15 @@ for cost in args.cost:
             sg.run_pass()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / args.steps * 1e3)
+        if args.events and args.launch == "pass" and len(ts) > 1:
+            sg.reserve_pass_events(20)
+            sg.pass_events = []
+            for _ in range(20):
+                sg.run_pass()
+            lt = sg.pass_launch_times_ms()
+            sg.pass_events = None
+            print("  rank %d: pass %.4f ms; launches A %.4f  B %.4f  tail %.4f  D %.4f" % (
+                len(ts) - 2, ts[-1], lt["pass_a"]["ms"], lt["pass_b"]["ms"], lt["pass_tail"]["ms"], lt["pass_dpquad"]["ms"]), flush=True)
         del sg
     ts = ts[1:]
     if args.json:

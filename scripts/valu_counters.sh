@@ -39,6 +39,9 @@ for k, v in sorted(tot.items()):
 key = "$wl" + ("" if not "$*".strip() else " " + "$*".strip())
 jf = "profiles/valu_counters.json"
 allj = json.load(open(jf)) if os.path.exists(jf) else {}
+import ctypes
+_lib = ctypes.CDLL("ocean_model_grid_generator_amd/csrc/libogg_hip.so"); _lib.ogg_version.restype = ctypes.c_char_p
+rec["_lib_src_hash"] = _lib.ogg_version().decode().split(" src ")[-1]
 allj[key] = rec
 allj["_source"] = "scripts/valu_counters.sh (rocprofv3 --pmc, a builder-side run of bench.py, NOT the process that printed a bench line); last updated for $tag"
 json.dump(allj, open(jf, "w"), indent=1, sort_keys=True)
