@@ -319,7 +319,9 @@ int ogg_fill_dev(long n, double value, double* out, void* stream);
 int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream);
 /* Self-test of the device-library functions the kernels restate with their coefficients as scalar operands (ogg_math.h,
  * ogg_bipolar_dev.h): which = 0: asin on [0, 1] (x); 1: atan (x, any); 2: atan2(y, x), finite; 3: 1.0 / x and 4: sqrt(x) without
- * scaling and special cases, 2^-700 <= x <= 2^700.  The number of k < n for which the
+ * scaling and special cases, 2^-700 <= x <= 2^700; 5: y / x without scaling, 2^-300 <= |x|, |y| <= 2^300 or y = +-0; 6: atan (x) and
+ * 7: atan2(y, x) with their coefficients in vector registers (the literal displaced-pole quadrature's forms); 8: atan2(y, x) with its
+ * quotient taken without scaling (finite arguments, the larger one within 2^-300 .. 2^300).  The number of k < n for which the
  * restatement differs IN ANY BIT from the library's own function is ADDED to *n_diff (device memory, 8 bytes, zeroed by the caller). */
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream);
 /* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:

@@ -19,8 +19,22 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
             a = atan2_lib(y[k], x[k]), b = atan2(y[k], x[k]);
         else if (which == 3)
             a = rcp_ieee_normal(x[k]), b = 1.0 / x[k];
-        else
+        else if (which == 4)
             a = sqrt_ieee_normal(x[k]), b = sqrt(x[k]);
+        else if (which == 5)
+            a = div_ieee_normal(y[k], x[k]), b = y[k] / x[k];
+        else if (which == 6 || which == 7) {   // the restatements with their coefficients in vector registers (the literal displaced-pole quadrature)
+            AtanVgpr c;
+            c.load(kAtanRed);
+            if (which == 6)
+                a = atan_lib_wave(x[k], c), b = atan(x[k]);
+            else
+                a = atan2_lib(y[k], x[k], c), b = atan2(y[k], x[k]);
+            c.keep();
+        } else {                              // which == 8: atan2 with the quotient taken without scaling, literal coefficients
+            const AtanLiterals c;
+            a = atan2_lib_normal(y[k], x[k], c), b = atan2(y[k], x[k]);
+        }
         diff = __double_as_longlong(a) != __double_as_longlong(b);
     }
     const unsigned long long m = __ballot(diff);
@@ -31,7 +45,8 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
 extern "C" {
 
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream) {
-    OGG_REQUIRE(which >= 0 && which <= 4 && n >= 0 && x && n_diff && (which != 2 || y), OGG_EARG, "ogg_libm_check: bad argument");
+    OGG_REQUIRE(which >= 0 && which <= 8 && n >= 0 && x && n_diff && ((which != 2 && which != 5 && which != 7 && which != 8) || y), OGG_EARG,
+                "ogg_libm_check: bad argument");
     if (n == 0) return OGG_OK;
     libm_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(which, n, x, y, n_diff);
     OGG_LAUNCH_CHECK();

@@ -13,6 +13,8 @@
 // The device code of the first two lives in ogg_dpole_dev.h (shared with the fused pass, ogg_pass.hip).
 #include <cstdlib>
 
+#include <cstring>
+
 #include "ogg_dpole_dev.h"
 
 namespace ogg {
@@ -348,7 +350,41 @@ template <int N, int ARC>
 __global__ __launch_bounds__(64 * DQ_WAVES, OGG_DQ_MINWAVES) void dpole_quad_kernel(DpQuadParams p) {
     __shared__ unsigned s_slot;
     const long t = (ARC == DP_ARC_LITERAL) ? take_ticket(p.ticket, &s_slot) : (long)blockIdx.x;
+#if OGG_DQ_RING == 3
+    if (ARC == DP_ARC_LITERAL) {
+        __shared__ DqLds<(ARC == DP_ARC_LITERAL) ? N : 1> lds;
+        dpole_quad_literal_lds<N>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx, reinterpret_cast<DqLds<N>&>(lds));
+        return;
+    }
+#elif OGG_DQ_RING > 0
+    if (ARC == DP_ARC_LITERAL) {
+        __shared__ double ring[(ARC == DP_ARC_LITERAL) ? dq_ring_doubles<N>() : 1];
+        dpole_quad_literal_ring<N, OGG_DQ_RING>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx,
+                                                ring + (threadIdx.x >> 6) * (OGG_DQ_RING * dq_ring_slot_doubles<N>()));
+        return;
+    }
+#endif
     dpole_quad_body<N, ARC>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
+}
+
+// the register-pipelined walk of the literal form (dpole_quad_body: one row of slack in registers, the library's own atan2 / atan, the
+// block-by-block look-back): an independently written second implementation, kept for OGG_DQ_WALK=regs -- the tests require the
+// LDS-pipelined walk to reproduce its bits
+template <int N>
+__global__ __launch_bounds__(64 * DQ_WAVES, OGG_DQ_MINWAVES) void dpole_quad_regs_kernel(DpQuadParams p) {
+    __shared__ unsigned s_slot;
+    const long t = take_ticket(p.ticket, &s_slot);
+    dpole_quad_body<N, DP_ARC_LITERAL>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
+}
+
+// error flag of a workspace the library allocated itself (it is returned to the stream-ordered allocator when the call returns, so the
+// caller could never ask): read back behind the kernels; synchronises the stream
+int check_own_workspace(const void* ws, hipStream_t s, const char* what) {
+    unsigned v = 0u;
+    OGG_HIP_CHECK(hipMemcpyAsync(&v, static_cast<const unsigned*>(ws) + 1, sizeof(v), hipMemcpyDeviceToHost, s));
+    OGG_HIP_CHECK(hipStreamSynchronize(s));
+    OGG_REQUIRE(v == 0u, OGG_EHIP, "%s: a look-back wait timed out (flag %u); results are invalid", what, v);
+    return OGG_OK;
 }
 
 __global__ __launch_bounds__(256) void dpole_mesh_reset_kernel(DpMeshParams m) { dpole_mesh_reset_body(m, blockIdx.x, gridDim.x); }
@@ -434,6 +470,7 @@ int ogg_displaced_pole_grid_angle_ws_dev(long Ni, long Nj, double lon0, double l
     OGG_LAUNCH_CHECK();
     dpole_mesh_kernel<<<(unsigned)dm_blocks(m), 64 * DM_WAVES, 0, s>>>(m);
     OGG_LAUNCH_CHECK();
+    if (!workspace) return check_own_workspace(ws, s, "ogg_displaced_pole_grid");
     return OGG_OK;
 }
 
@@ -511,20 +548,27 @@ int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx
                            ws_bytes, ogg::quad_nodes_host(order), p))
         return e;
     const unsigned nwg = (unsigned)(p.gx * p.n_chunks);
+    const char* walk = getenv("OGG_DQ_WALK");
+    const bool regs = walk && strcmp(walk, "regs") == 0;   // the second implementation of the literal walk (tests)
     if (order == 2) {
         dpole_quad_tables_kernel<2><<<(unsigned)dpole_quad_tables_blocks<2>(p), 256, 0, s>>>(p);
         if (arc_form == OGG_DP_ARC_CHORD)
             dpole_quad_kernel<2, DP_ARC_CHORD><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
+        else if (regs)
+            dpole_quad_regs_kernel<2><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
         else
             dpole_quad_kernel<2, DP_ARC_LITERAL><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
     } else {
         dpole_quad_tables_kernel<4><<<(unsigned)dpole_quad_tables_blocks<4>(p), 256, 0, s>>>(p);
         if (arc_form == OGG_DP_ARC_CHORD)
             dpole_quad_kernel<4, DP_ARC_CHORD><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
+        else if (regs)
+            dpole_quad_regs_kernel<4><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
         else
             dpole_quad_kernel<4, DP_ARC_LITERAL><<<nwg, 64 * DQ_WAVES, 0, s>>>(p);
     }
     OGG_LAUNCH_CHECK();
+    if (!workspace && arc_form == OGG_DP_ARC_LITERAL) return check_own_workspace(ws, s, "ogg_displaced_pole_metrics_quad");
     return OGG_OK;
 }
 

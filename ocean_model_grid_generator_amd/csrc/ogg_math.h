@@ -78,6 +78,20 @@ OGG_DEV double sqrt_ieee_normal(double x) {
     return fma(fma(-g, g, x), h, g);
 }
 
+// a / b for operands within 2^-300 .. 2^300 in magnitude (a may also be a signed zero): the compiler's own expansion of the IEEE
+// division -- reciprocal seed, two coupled refinements, quotient, one residual correction -- without v_div_scale / v_div_fmas /
+// v_div_fixup (9 instead of 11 instructions; the same bits: v_div_scale only acts when an operand is near the ends of the exponent
+// range or the exponents differ by 768 or more, without scaling v_div_fmas IS the fma, and of what v_div_fixup repairs only the sign
+// of a zero quotient can occur here -- the residual step turns -0 into +0 --, which the quotient's own sign restores).  Bit-identity
+// is a test (ogg_libm_check_dev, which = 5).
+OGG_DEV double div_ieee_normal(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(fma(-b, y, 1.0), y, y);
+    y = fma(fma(-b, y, 1.0), y, y);
+    const double q = a * y;
+    return copysign(fma(fma(-b, q, a), y, q), q);
+}
+
 struct cplx {
     double re, im;
 };
@@ -107,6 +121,21 @@ OGG_DEV cplx cdiv(cplx a, cplx b) {
     return o;
 }
 
+// The same division for operands known to be normal (|b| within 2^+-300, a zero or normal; see div_ieee_normal), without a branch:
+// the two arms of Smith's algorithm differ only in which component plays which part, and a + b = b + a, so selects give the same bits.
+OGG_DEV cplx cdiv_normal(cplx a, cplx b) {
+    const bool re_big = fabs(b.re) >= fabs(b.im);
+    const double big = re_big ? b.re : b.im, small = re_big ? b.im : b.re;
+    const double p = re_big ? a.re : a.im, m = re_big ? a.im : a.re;   // o.re = (p + m rat) scl in both arms
+    const double rat = div_ieee_normal(small, big);
+    const double scl = rcp_ieee_normal(big + small * rat);
+    cplx o;
+    o.re = (p + m * rat) * scl;
+    const double d = m - p * rat;            // re_big: a.im - a.re rat;  else: -(a.im rat - a.re)
+    o.im = (re_big ? d : -d) * scl;
+    return o;
+}
+
 // numpy.absolute(complex128): max * sqrt(1 + (min/max)^2) with one fma.
 OGG_DEV double cabs_np(cplx w) {
     const double ar = fabs(w.re), ai = fabs(w.im);
@@ -114,6 +143,13 @@ OGG_DEV double cabs_np(cplx w) {
     if (a == 0.0) return 0.0;
     const double r = b / a;
     return a * sqrt_ieee_normal(fma(r, r, 1.0));   // the argument lies in [1, 2]: IEEE sqrt, the same bits, without its scaling / special cases
+}
+// for a normal, non-zero larger component (no branch, no scaling in the division)
+OGG_DEV double cabs_np_normal(cplx w) {
+    const double ar = fabs(w.re), ai = fabs(w.im);
+    const double a = fmax(ar, ai), b = fmin(ar, ai);
+    const double r = div_ieee_normal(b, a);
+    return a * sqrt_ieee_normal(fma(r, r, 1.0));
 }
 
 // 1/x and 1/sqrt(x) for NORMAL, positive x from the hardware seed (v_rcp_f64 / v_rsq_f64, relative error e <= 2^-24 measured,
@@ -198,12 +234,77 @@ static __constant__ double kAtanRed[20] = {-0x1.5555555555523p-2, 0x1.9999999995
 
 typedef ScalarPoly<20> AtanCoefs;   // AtanCoefs c; c.load(kAtanRed); ... atan2_lib(y, x, c) ...; c.keep();
 
-OGG_DEV double atanred_lib(double v, const AtanCoefs& c) {   // |v| <= 1
+// The same polynomial with its coefficients as literals in the code (the compiler materialises each with two s_mov_b32 or two v_mov_b32
+// in front of its fma, as it does for the library's own polynomials).
+struct AtanLiterals {
+    OGG_DEV double eval(double z) const {
+        constexpr double k[20] = {-0x1.5555555555523p-2, 0x1.99999999952ccp-3,  -0x1.2492492376b7dp-3, 0x1.c71c717e1913cp-4,
+                                  -0x1.745d119378e4fp-4, 0x1.3b13657b87036p-4,  -0x1.110e48b207f05p-4, 0x1.e1bb48427b883p-5,
+                                  -0x1.ae5ce6a214619p-5, 0x1.82d5d6ef28734p-5,  -0x1.59976e82d3ff0p-5, 0x1.2c15b5711927ap-5,
+                                  -0x1.e9ae6fc27006ap-6, 0x1.67e295f08b19fp-6,  -0x1.c6ea4a57d9582p-7, 0x1.d6d43a595c56fp-8,
+                                  -0x1.7952daf56de9bp-9, 0x1.b2bb069efb384p-11, -0x1.3e260bd3237f4p-13, 0x1.ba404b5e68a13p-17};
+        double p = k[19];
+#pragma unroll
+        for (int i = 18; i >= 0; --i) p = fma(p, z, k[i]);
+        return p;
+    }
+    OGG_DEV void load(const double*) {}
+    OGG_DEV void keep() const {}
+};
+
+// ... and with its coefficients resident in VECTOR registers (40 of them), for a kernel that has vector registers to spare but no scalar
+// ones (a wave limited to two per SIMD by its other state): load() once in front of the loop.  The fma is written as the three-address
+// VOP3 instruction -- left to itself the compiler takes the two-address v_fmac_f64 and copies the coefficient in front of every step
+// (v_mov_b64 + v_fmac_f64: two vector instructions per Horner step; measured 3.8 against 2.1 ns per step, scripts/microbench/horner_issue.hip).
+struct AtanVgpr {
+    double k[20];
+    OGG_DEV void load(const double* table) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            k[i] = table[i];
+            asm volatile("" : "+v"(k[i]));
+        }
+    }
+    OGG_DEV double eval(double z) const {
+        double p;   // the whole chain in one asm statement (the compiler pads every asm statement with wait states of its own)
+        asm("v_fma_f64 %0, %21, %1, %20\n\t"
+            "v_fma_f64 %0, %0, %1, %19\n\t"
+            "v_fma_f64 %0, %0, %1, %18\n\t"
+            "v_fma_f64 %0, %0, %1, %17\n\t"
+            "v_fma_f64 %0, %0, %1, %16\n\t"
+            "v_fma_f64 %0, %0, %1, %15\n\t"
+            "v_fma_f64 %0, %0, %1, %14\n\t"
+            "v_fma_f64 %0, %0, %1, %13\n\t"
+            "v_fma_f64 %0, %0, %1, %12\n\t"
+            "v_fma_f64 %0, %0, %1, %11\n\t"
+            "v_fma_f64 %0, %0, %1, %10\n\t"
+            "v_fma_f64 %0, %0, %1, %9\n\t"
+            "v_fma_f64 %0, %0, %1, %8\n\t"
+            "v_fma_f64 %0, %0, %1, %7\n\t"
+            "v_fma_f64 %0, %0, %1, %6\n\t"
+            "v_fma_f64 %0, %0, %1, %5\n\t"
+            "v_fma_f64 %0, %0, %1, %4\n\t"
+            "v_fma_f64 %0, %0, %1, %3\n\t"
+            "v_fma_f64 %0, %0, %1, %2"
+            : "=&v"(p)
+            : "v"(z), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]), "v"(k[8]), "v"(k[9]), "v"(k[10]),
+              "v"(k[11]), "v"(k[12]), "v"(k[13]), "v"(k[14]), "v"(k[15]), "v"(k[16]), "v"(k[17]), "v"(k[18]), "v"(k[19]));
+        return p;
+    }
+    OGG_DEV void keep() const {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) asm volatile("" ::"v"(k[i]));
+    }
+};
+
+template <class C>
+OGG_DEV double atanred_lib(double v, const C& c) {   // |v| <= 1
     const double t = v * v;
     return fma(v, t * c.eval(t), v);
 }
 
-OGG_DEV double atan_lib(double x, const AtanCoefs& c) {
+template <class C>
+OGG_DEV double atan_lib(double x, const C& c) {
     const double v = fabs(x);
     const bool g = v > 1.0;
     const double a = atanred_lib(g ? 1.0 / v : v, c);
@@ -211,7 +312,35 @@ OGG_DEV double atan_lib(double x, const AtanCoefs& c) {
     return copysign(r, x);
 }
 
-OGG_DEV double atan2_lib(double y, double x, const AtanCoefs& c) {   // finite arguments
+// atan_lib with the reciprocal of arguments above 1 behind a wave-uniform branch: a wave whose arguments are all <= 1 in magnitude (the
+// tangent of a cap's colatitude: every wave of a southern cap) does not pay for a division whose result a select would discard
+template <class C>
+OGG_DEV double atan_lib_wave(double x, const C& c) {
+    if (__builtin_expect(__ballot(fabs(x) > 1.0) != 0ull, 0)) return atan_lib(x, c);
+    return copysign(atanred_lib(fabs(x), c), x);
+}
+
+// atan(x) for |x| <= 1 (the caller's guarantee: nothing to invert), the same bits as atan_lib / atan
+template <class C>
+OGG_DEV double atan_lib_le1(double x, const C& c) {
+    return copysign(atanred_lib(fabs(x), c), x);
+}
+
+// atan2 for finite arguments of which the larger is normal (|.| within 2^+-300) or both are zero: the quotient without scaling
+template <class C>
+OGG_DEV double atan2_lib_normal(double y, double x, const C& c) {
+    const double ay = fabs(y), ax = fabs(x);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    double a = atanred_lib(div_ieee_normal(mn, mx), c);     // 0 / 0: NaN, replaced below (y == 0)
+    const bool xneg = __double2hiint(x) < 0;
+    a = (ax < ay) ? 0x1.921fb54442d18p+0 - a : a;
+    a = xneg ? 0x1.921fb54442d18p+1 - a : a;
+    a = (y == 0.0) ? (xneg ? 0x1.921fb54442d18p+1 : 0.0) : a;
+    return copysign(a, y);
+}
+
+template <class C>
+OGG_DEV double atan2_lib(double y, double x, const C& c) {   // finite arguments
     const double ay = fabs(y), ax = fabs(x);
     const double mx = fmax(ax, ay), mn = fmin(ax, ay);
     double a = atanred_lib(mn / mx, c);

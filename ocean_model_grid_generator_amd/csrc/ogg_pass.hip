@@ -196,12 +196,24 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     }
 }
 
+#ifndef OGG_DQ_MINWAVES_PASS
+#define OGG_DQ_MINWAVES_PASS 2
+#endif
 // launch D: the displaced-pole quadrature in the reference's literal arithmetic (238 VGPRs: its own launch)
 template <int N>
-__global__ __launch_bounds__(PASS_TX, 2) void pass_d_kernel(DpQuadParams p) {
+__global__ __launch_bounds__(PASS_TX, OGG_DQ_MINWAVES_PASS) void pass_d_kernel(DpQuadParams p) {
     __shared__ unsigned s_slot;
     const long t = take_ticket(p.ticket, &s_slot);
+#if OGG_DQ_RING == 3
+    __shared__ DqLds<N> lds;
+    dpole_quad_literal_lds<N>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx, lds);
+#elif OGG_DQ_RING > 0
+    __shared__ double ring[dq_ring_doubles<N>()];
+    dpole_quad_literal_ring<N, OGG_DQ_RING>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx,
+                                            ring + (threadIdx.x >> 6) * (OGG_DQ_RING * dq_ring_slot_doubles<N>()));
+#else
     dpole_quad_body<N, DP_ARC_LITERAL>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
+#endif
 }
 
 long env_long(const char* name, long dflt) {
@@ -394,11 +406,35 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     if (int e = mark(3)) return e;
     if (dq_literal) {
         const unsigned nd = (unsigned)(dq.gx * dq.n_chunks);
+#ifdef OGG_DQ_PROFILE
+        {
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dq_prof), z, sizeof(z)));
+            unsigned long long z3[3][8] = {};
+            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dq_prof_strip), z3, sizeof(z3)));
+        }
+#endif
         if (scap->order == 2)
             pass_d_kernel<2><<<nd, PASS_TX, 0, st>>>(dq);
         else
             pass_d_kernel<4><<<nd, PASS_TX, 0, st>>>(dq);
         OGG_LAUNCH_CHECK();
+#ifdef OGG_DQ_PROFILE
+        if (getenv("OGG_DQ_PROFILE")) {
+            OGG_HIP_CHECK(hipStreamSynchronize(st));
+            unsigned long long v[8];
+            OGG_HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dq_prof), sizeof(v)));
+            const double w = (double)v[5], rows = (double)v[4];
+            fprintf(stderr, "dq profile: %.0f waves, %.1f lattice rows per wave; cycles per lattice row: probes %.0f, probes + maps + publish %.0f, look-back resolve %.0f, "
+                            "resolve + haversines + sums %.0f, whole iteration %.0f; walk %.0f cycles per wave\n", w, rows / w, (double)v[0] / rows,
+                    (double)v[1] / rows, (double)v[2] / rows, (double)v[3] / rows, (double)v[7] / rows, (double)v[6] / w);
+            unsigned long long b[3][8];
+            OGG_HIP_CHECK(hipMemcpyFromSymbol(b, HIP_SYMBOL(g_dq_prof_strip), sizeof(b)));
+            fprintf(stderr, "  by eighth of the row, resolve / iteration cycles per lattice row:");
+            for (int k = 0; k < 8; ++k) fprintf(stderr, "  %.0f / %.0f", (double)b[0][k] / (double)b[2][k], (double)b[1][k] / (double)b[2][k]);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     return mark(4);
 }

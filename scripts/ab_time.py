@@ -32,7 +32,10 @@ for rnd in range(args.rounds):
             res.setdefault((wl, lib), []).append((d["ms_per_step"], (d["pass_launches"] or {}).get("pass_b", {}).get("ms")))
             kern = {k: round(v["mean_ms"], 4) for k, v in (d.get("kernels") or {}).items()}
             res.setdefault((wl, lib, "kernels"), []).append(kern)
-            print(rnd, wl, os.path.basename(lib), "%.4f" % d["ms_per_step"], (d["pass_launches"] or {}).get("pass_b", {}).get("ms"), kern, flush=True)
+            pl = d["pass_launches"] or {}
+            cs = d.get("field_checksums") or {}
+            sig = {k: "".join(v[f][-4:] for f in ("x", "y", "dx", "dy", "area", "angle_dx")) for k, v in cs.items() if isinstance(v, dict)}   # bit fingerprints, shortened
+            print(rnd, wl, os.path.basename(lib), "%.4f" % d["ms_per_step"], {k: round(v["ms"], 4) for k, v in pl.items()}, kern, sig, flush=True)
 summary = {"%s|%s" % k: {"ms_per_step": [a for a, _ in v], "pass_b_ms": [b for _, b in v], "best_ms_per_step": min(a for a, _ in v),
                              "stand_alone_kernels_ms": res[k + ("kernels",)]} for k, v in res.items() if len(k) == 2}
 print(json.dumps(summary))

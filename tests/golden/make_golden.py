@@ -62,6 +62,8 @@ CONFIGS = {
 BIG = {
     "r8": dict(inverse_resolution=8.0),                                                       # BASELINE config 2
     "r8_latdp": dict(inverse_resolution=8.0, lon_dp=80.0, lat_dp=-85.85),                     # BASELINE config 3
+    # the reference's own 1/8 degree test configuration (t/test_ocean_grid_gen.py:176-185, extras/Makefile:40-41): 4481 x 5761
+    "r8_p125": dict(inverse_resolution=8.0, r_dp=0.2, south_cutoff_row=5, match_dy=["bp", "so", "p125sc"], ensure_nj_even=True),
 }
 SAVE_FULL = ("r0.25_even", "r0.5_dp")
 
@@ -212,6 +214,8 @@ def check_oracle_functions(v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also hash the 1/8 degree configurations (minutes of CPU)")
+    ap.add_argument("--only", nargs="*", default=None, help="run just these configurations (names of CONFIGS / BIG); the others keep their "
+                    "recorded hashes (same platform fingerprint required)")
     args = ap.parse_args()
     ogg = load_reference()
 
@@ -226,10 +230,14 @@ def main():
     if os.path.exists(hashes_path):
         old = json.load(open(hashes_path))
         if old.get("platform_fingerprint") == record["platform_fingerprint"]:
-            record["configs"].update({k: v for k, v in old["configs"].items() if k in BIG})
+            record["configs"].update({k: v for k, v in old["configs"].items() if k in BIG or args.only is not None})
+        elif args.only is not None:
+            raise SystemExit("--only needs the recorded platform fingerprint to match this machine's")
     todo = dict(CONFIGS)
     if args.big:
         todo.update(BIG)
+    if args.only is not None:
+        todo = {k: v for k, v in {**CONFIGS, **BIG}.items() if k in args.only}
     for name, flags in todo.items():
         ref = run_reference(ogg, flags)
         r, kw = oracle_flags(flags)

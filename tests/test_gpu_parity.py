@@ -295,6 +295,45 @@ def test_rcp_and_sqrt_without_scaling_equal_the_ieee_operations(hip):
     assert _libm_check(4, x) == 0
 
 
+def test_division_without_scaling_and_vector_register_arctangents_equal_the_library(hip):
+    """The forms the literal displaced-pole quadrature takes (ogg_math.h): y / x without v_div_scale / v_div_fmas / v_div_fixup for
+    operands within 2^-300 .. 2^300 (or y = +-0); atan / atan2 with their coefficients in vector registers and the fma chain as one asm
+    statement; atan2 with its quotient taken without scaling.  Every bit against the device library, 2e7 arguments each."""
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(14)
+    n = 20_000_000
+
+    def spread(k, emax):
+        m = torch.rand(k, dtype=torch.float64, device="cuda:0", generator=g) + 1.0
+        e = torch.randint(-emax, emax, (k,), device="cuda:0", generator=g).to(torch.float64)
+        sgn = torch.randint(0, 2, (k,), device="cuda:0", generator=g).to(torch.float64) * 2 - 1
+        return sgn * m * torch.exp2(e)
+
+    x, y = spread(n, 300), spread(n, 300)
+    q = n // 4
+    x[:q] = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) * 4 - 2        # the quadrature's own range: O(1) operands
+    y[:q] = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) * 4 - 2
+    y[q: q + 1000] = x[q: q + 1000]
+    y[q + 1000: q + 2000] = 0.0
+    y[q + 2000: q + 3000] = -0.0
+    assert _libm_check(5, x, y) == 0
+    assert _libm_check(8, x, y) == 0
+    x2, y2 = spread(n, 300), spread(n, 300)
+    x2[:q] = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) * 4 - 2
+    y2[:q] = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) * 4 - 2
+    fy = torch.tensor([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, 0.0, -0.0, 3.0, 5e-324], dtype=torch.float64, device="cuda:0")
+    fx = torch.tensor([0.0, 0.0, -0.0, -0.0, 0.0, -0.0, 2.0, -2.0, -5e-324, 1.7e308], dtype=torch.float64, device="cuda:0")
+    y2[-fy.numel():] = fy
+    x2[-fx.numel():] = fx
+    assert _libm_check(7, x2, y2) == 0
+    sp = torch.tensor([0.0, -0.0, 1.0, -1.0, np.nextafter(1.0, 2), np.nextafter(1.0, 0), 5e-324, -5e-324, 1.7e308, -1.7e308,
+                       float("inf"), float("-inf")], dtype=torch.float64, device="cuda:0")
+    x2[-sp.numel():] = sp
+    assert _libm_check(6, x2) == 0
+    x3 = torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) * 2 - 1           # |x| <= 1 everywhere: the wave-uniform short path
+    assert _libm_check(6, x3) == 0
+
+
 def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
     got = []
     for rows in ("8", "1", "5", "32"):
@@ -426,6 +465,24 @@ def test_displaced_pole_quad_vs_oracle(ogg, Ni, Nj, r_dp, order, arc_form):
     assert max(rel) < dp_quad_rel_tol(Ni)
     for g, w in zip(got, want):                       # doughnut rows incl. the pole: relative to the field scale
         assert maxabs(g, w) <= dp_quad_rel_tol(Ni) * np.abs(w).max()
+
+
+@pytest.mark.parametrize("Ni,Nj,kw,order", [(72, 14, dict(r_dp=0.2), 4), (72, 14, dict(r_dp=0.2), 2), (100, 9, dict(r_dp=0.35), 4),
+                                            (720, 70, dict(r_dp=0.2), 4), (1440, 140, dict(r_dp=0.34135899793333113), 4),
+                                            (2880, 40, dict(r_dp=0.05), 4)])
+def test_literal_quad_walks_agree_bitwise(ogg, monkeypatch, Ni, Nj, kw, order):
+    """Two independently written walks of the literal displaced-pole quadrature must give the same BITS: the LDS-pipelined one (pending
+    rows in an LDS ring, batched look-back, restated arctangents with their coefficients in vector registers) and the register-pipelined
+    one (OGG_DQ_WALK=regs: block-by-block look-back, the device library's own atan2 / atan).  A wrong unwrap state -- both probes of a pair
+    lowered by 360 degrees or neither -- changes dx, dy, area by 1e-10 relative only, below what a comparison with the CPU oracle at its
+    libm-noise tolerance can see; bit-identity of two implementations sees it (this test failed on a maps bug that every tolerance test
+    passed)."""
+    monkeypatch.delenv("OGG_DQ_WALK", raising=False)
+    a = ogg.displacedPoleCap_metrics_quad(order, Ni, Nj, -300.0, -78.0, 80.0, kw["r_dp"])
+    monkeypatch.setenv("OGG_DQ_WALK", "regs")
+    b = ogg.displacedPoleCap_metrics_quad(order, Ni, Nj, -300.0, -78.0, 80.0, kw["r_dp"])
+    for x, y, f in zip(a, b, ("dx", "dy", "area")):
+        assert np.array_equal(x, y), (f, float(np.abs(x - y).max()), int((x != y).sum()))
 
 
 def test_displaced_pole_quad_bands_are_bit_identical(hip):
