@@ -146,6 +146,20 @@ def test_midas_mercator_r8_band(ogg):
     assert np.array_equal(ogg.angle_x(xo, yo), orc.angle_x(xo, yo))     # atan2(0, +) == 0 on a lat-lon mesh
 
 
+def test_midas_mercator_r16_band(ogg):
+    """The same at 1/16 degree width (11521 columns, BASELINE config 5), 200 rows of the Mercator sub-grid either side of 50 S."""
+    phi = orc.phi_mercator(11520, np.arange(-2909, 2691 + 1))
+    j0 = int(np.searchsorted(phi, -50.0)) - 100
+    lam = -300.0 + np.arange(11521) * 360 / float(11520)
+    xo = np.ascontiguousarray(np.tile(lam, (201, 1)))
+    yo = np.ascontiguousarray(np.tile(phi[j0:j0 + 201].reshape(-1, 1), (1, 11521)))
+    dx, dy, area = ogg.generate_grid_metrics_MIDAS(xo, yo)
+    odx, ody, oar = orc.generate_grid_metrics_MIDAS(xo, yo)
+    record("midas_r16_band", dx=maxabs(dx, odx), dy=maxabs(dy, ody), area=maxabs(area, oar), area_rel=maxrel(area, oar))
+    assert maxrel(dx, odx) < 2e-15 and maxrel(dy, ody) < 2e-15 and maxrel(area, oar) < 5e-12
+    assert np.array_equal(ogg.angle_x(xo, yo), orc.angle_x(xo, yo))
+
+
 def test_angle_shape_error(ogg):
     with pytest.raises(Exception, match="same shape"):
         ogg.angle_x(np.zeros((3, 4)), np.zeros((3, 5)))
@@ -167,7 +181,8 @@ def test_bipolar_projection_golden_special_points(ogg, fvec):
     assert np.array_equal(hi2, hi) and np.array_equal(hj2, hj)
 
 
-@pytest.mark.parametrize("Ni,Nj,lat0", [(48, 10, 64.05895973), (1440, 238, 64.97316302279852), (5760, 960, 64.03160594077568)])
+@pytest.mark.parametrize("Ni,Nj,lat0", [(48, 10, 64.05895973), (1440, 238, 64.97316302279852), (5760, 960, 64.03160594077568),
+                                        (11520, 1920, 64.04528618884338)])
 def test_bipolar_cap_mesh(ogg, fvec, Ni, Nj, lat0):
     lams, phis, hi, hj = ogg.generate_bipolar_cap_mesh(Ni, Nj, lat0, -300.0, ensure_nj_even=False)
     ol, op, ohi, ohj = orc.generate_bipolar_cap_mesh(Ni, Nj, lat0, -300.0, False)
@@ -376,6 +391,32 @@ def test_bipolar_quad_full_size_r8_by_zone(ogg):
         assert maxabs(got[2][a:b], want[2][a:b]) < 1e-6                # north_star: area diff < 1e-6 m^2
     record("bp_quad_r8_zones", **{"%s_%d" % k: v for k, v in worst.items()})
     assert max(worst.values()) < 5e-14
+
+
+def test_bipolar_quad_full_size_r16_by_zone(ogg):
+    """BASELINE config 5's cap (11520 x 1920 cells, 1/16 degree) against the oracle by zones -- the joint, mid-cap, 88 degrees (where the
+    guarded rows begin), 89 degrees, the pole rows -- at the bounds of the 1/8 degree test: pole-adjacent cells are half the size here and
+    the literal sequence of OGG:69-79 loses more digits there, which the guard (K = 4000) and the literal fix-up must absorb."""
+    Ni, Nj, lat0 = 11520, 1920, 64.04528618884338
+    rp = np.tan(0.5 * (90 - lat0) * orc.PI_180)
+    got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp)
+    worst, worst_area = {}, 0.0
+    for a, b in ((0, 16), (950, 966), (1764, 1780), (1838, 1854), (1888, 1920)):
+        want = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, -300.0, rp, rows_per_chunk=4, j_first=a, j_last=b)
+        for g, w, name in zip(got, want, ("dx", "dy", "area")):
+            gg, ww = g[a:b], w[a:b]
+            m = ww != 0
+            assert np.array_equal(gg[~m], ww[~m])                      # dy == 0 on the meridians alpha2 == 1
+            worst[(name, a)] = float((np.abs(gg - ww)[m] / np.abs(ww[m])).max())
+        worst_area = max(worst_area, maxabs(got[2][a:b], want[2][a:b]))
+        del want
+    record("bp_quad_r16_zones", area_max_abs=worst_area, **{"%s_%d" % k: v for k, v in worst.items()})
+    assert worst_area < 1e-6                                            # north_star: area diff < 1e-6 m^2 (measured 7.2e-8)
+    # the cells that touch the two pole points (last zone): 6.0e-14 relative in area WITH EVERY CELL LITERAL (OGG_BP_GUARD_K=0,
+    # scripts/guard_k_probe.py r16: ocml against the host libm through the reference's own acos -> tan -> atan -> cos round trip); the
+    # guard (K = 4000) adds nothing to it (dx 1.6e-14, dy 1.9e-14, area 6.0e-14 with and without)
+    pole_area = worst.pop(("area", 1888))
+    assert pole_area < 2e-13 and max(worst.values()) < 5e-14, (pole_area, worst)
 
 
 def test_bipolar_cap_ij_array(ogg):

@@ -471,6 +471,30 @@ def test_full_size_properties_r8(sg):
     assert abs(col[jM] / col[jM - 1] - 1) < 0.02
 
 
+def test_reference_own_r8_test_configuration_through_main_vs_oracle(hip):
+    """The reference's own 1/8 degree test configuration (t/test_ocean_grid_gen.py:176-185, extras/Makefile:40-41):
+    -r 8 --r_dp 0.2 --south_cutoff_row 5 --match_dy bp so p125sc --ensure_nj_even, 4481 x 5761, through the drop-in main() (plan, one
+    device-resident pass, stitching) against the oracle, every element; shapes and sub-grid sizes as recorded from the unmodified reference
+    (tests/golden/ref_hashes.json: r8_p125; tests/golden/make_golden.py asserted the oracle bit-identical to the reference on it, and
+    where this host's numpy / libm fingerprint equals the recorded one the oracle's sha256 per field is checked again here)."""
+    import hashlib
+    import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+    from test_oracle_golden import SAME_PLATFORM
+    rec = json.load(open(os.path.join(GOLD, "ref_hashes.json")))
+    cfg = rec["configs"]["r8_p125"]
+    flags = dict(cfg["flags"])
+    got = ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, **flags)
+    for f, shp in cfg["shapes"].items():
+        assert list(got[f].shape) == shp, (f, got[f].shape, shp)
+    assert got["x"].shape == (4481, 5761)
+    r = flags.pop("inverse_resolution")
+    want = orc.make_supergrid(r, skip_doughnut_rows=True, **flags)
+    if SAME_PLATFORM:
+        for f in FIELDS:
+            assert hashlib.sha256(np.ascontiguousarray(want[f], dtype=np.float64).tobytes()).hexdigest() == cfg["sha256"][f], f
+    _check_supergrid(got, want, "r8_p125")
+
+
 @pytest.mark.parametrize("world,rank", [(1, 0), (8, 7)])
 def test_full_size_properties_r16_on_device(sg, world, rank):
     """BASELINE config 5 (1/16 degree, 101 M cells, 4.9 GB of fields) through the fused pass, checked where the fields are:
