@@ -309,6 +309,15 @@ long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows);
 int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
                            const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** events5, double* alg_bytes4,
                            void* stream);
+/* The same in two steps, for a caller that runs the pass of one set of bands many times (a rank's step loop): the plan holds the kernel
+ * parameters of the launches, their grid sizes and the tiling knobs (the OGG_* environment variables are read when the plan is BUILT), so
+ * that a run costs the host its launches and nothing else -- no validation, no planning, no getenv.  The band descriptors are copied:
+ * they may be freed after ogg_supergrid_pass_plan_dev returns; the buffers and workspaces they point to must stay.  One pass at a time per
+ * plan (its cap workspaces are the plan's).  ogg_supergrid_pass_dev == plan + run + destroy. */
+int ogg_supergrid_pass_plan_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                                const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** plan_out);
+int ogg_supergrid_pass_run_dev(const void* plan, void** events5, double* alg_bytes4, void* stream);
+int ogg_supergrid_pass_plan_destroy(void* plan);
 
 /* ------------------------------------------------------------------------------------------------------
  * Device utilities used by the band-sharded pipeline (bench / multi-GPU)

@@ -126,6 +126,10 @@ SIGNATURES = {
     "ogg_supergrid_pass_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
                                ctypes.POINTER(BipolarBand), ctypes.POINTER(DpoleBand), ctypes.POINTER(c_void_p), ctypes.POINTER(c_double),
                                c_void_p],
+    "ogg_supergrid_pass_plan_dev": [c_int, ctypes.POINTER(LatlonBand), c_long, c_double, c_double, c_double, c_int,
+                                    ctypes.POINTER(BipolarBand), ctypes.POINTER(DpoleBand), ctypes.POINTER(c_void_p)],
+    "ogg_supergrid_pass_run_dev": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_double), c_void_p],
+    "ogg_supergrid_pass_plan_destroy": [c_void_p],
     "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],

@@ -20,10 +20,13 @@
 // stand-alone kernels of ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level
 // entry points.
 #include <cstring>
+#include <new>
 
 #include "ogg_bipolar_dev.h"
 #include "ogg_dpole_dev.h"
 #include "ogg_latlon_fused_dev.h"
+
+extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows);
 
 namespace {
 
@@ -267,24 +270,34 @@ double dpole_quad_bytes(const ogg_dpole_band& d) {
     return 8.0 * ((double)d.n_pt_rows * (double)d.Ni + (double)d.n_cell_rows * (2.0 * (double)d.Ni + 1.0));
 }
 
+// Everything a pass needs that does not change from one call to the next: the kernel parameters of the launches, their grid sizes,
+// the bytes they write.  Built once per (bands, knobs) by build_pass_plan -- the environment knobs are read THERE -- and replayed by
+// run_pass_plan, whose host work is the launches themselves.
+struct PassPlan {
+    int order;                 // Gauss-Lobatto order the bipolar kernels are instantiated for
+    PassAParams A;
+    PassBParams B;
+    QuadPlan qp;
+    DpQuadParams dq;
+    int dq_order;
+    bool have_quad, dq_literal, launch_b;
+    unsigned na, nb, nd;
+    double alg_bytes[4];
+};
+
 template <int N>
-int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, const ogg_dpole_band* scap, hipEvent_t* ev,
-                double* alg_bytes4, hipStream_t st) {
-    // ev: NULL, or 5 events (entries may be NULL) recorded before launch A and after launches A, B, C and D (bench.py times the
-    // launches with them)
-    auto mark = [&](int k) -> int {
-        if (ev && ev[k]) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
-        return OGG_OK;
-    };
+int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_band* cap, const ogg_dpole_band* scap, PassPlan& P) {
+    P = PassPlan{};
+    P.order = N;
     const long n_strips_ll = ll.n_bands ? ll.strip0[ll.n_bands] : 0;
     const bool have_cap = cap && cap->n_pt_rows > 0;
     const bool have_quad = have_cap && metrics;
     const bool have_dp = scap && scap->n_pt_rows > 0;
     const bool have_dquad = have_dp && metrics;
     const bool dq_literal = have_dquad && scap->arc_form == OGG_DP_ARC_LITERAL;
-    PassAParams A{};
-    PassBParams B{};
-    QuadPlan qp{};
+    PassAParams& A = P.A;
+    PassBParams& B = P.B;
+    QuadPlan& qp = P.qp;
     A.ll = ll, B.ll = ll;
     if (have_cap) {
         A.mesh = MeshParams{cap->Ni, cap->Nj, cap->lat0_bp, cap->lon_bp, cap->j0, cap->n_pt_rows, cap->x, cap->y, nullptr, nullptr, cap->angle, MESH_ROWS};
@@ -304,7 +317,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.gx * qp.guard.gy : 0;
         B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.gx * qp.fast.gy : 0;
     }
-    DpQuadParams dq{};
+    DpQuadParams& dq = P.dq;
     if (have_dp) {   // workspace of the band: [mesh words][quadrature tables and words]
         const DpGeom g{scap->Ni, scap->Nj, scap->lon0, scap->lat0, scap->lon_dp, scap->r_dp};
         const long mesh_ws = (long)((dm_workspace_bytes(scap->Ni, scap->n_pt_rows) + 255) / 256 * 256);
@@ -321,6 +334,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
             A.dq = dq, A.dq_order = scap->order;
             A.n_dq_tab = scap->order == 2 ? dpole_quad_tables_blocks<2>(dq) : dpole_quad_tables_blocks<4>(dq);
             if (!dq_literal) B.dq = dq, B.dq_order = scap->order, B.n_dquad = dq.gx * dq.n_chunks;
+            P.dq_order = scap->order;
         }
     }
     // With metrics, launch A builds only the tables and launch B carries everything else, the cap meshes included: one long launch
@@ -333,25 +347,19 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
         B.mesh = A.mesh, B.mesh_gx = A.mesh_gx, B.n_mesh = A.n_mesh;
         A.n_mesh = 0;
     }
-    if (alg_bytes4) {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
+    {  // algorithmic bytes written by each launch (bench.py prices the launches against the HBM roofline)
         const double ni = (double)(ni1 - 1);
         const double mesh_bytes = have_cap ? 8.0 * 3.0 * (double)cap->n_pt_rows * (double)ni1 : 0.0;
         const double bq_bytes = have_quad ? 8.0 * (double)cap->n_cell_rows * (3.0 * ni + 1.0) : 0.0;
-        alg_bytes4[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes) + ((have_quad && qp.has_top) ? 8.0 * ni : 0.0);   // + dxq[ny]
-        alg_bytes4[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + bq_bytes + mesh_bytes + (have_dp ? dpole_mesh_bytes(*scap) : 0.0) +
-                                       ((have_dquad && !dq_literal) ? dpole_quad_bytes(*scap) : 0.0)
-                                 : 0.0;
-        alg_bytes4[2] = 0.0;   // the tail rewrites cells launch B has written: no bytes of its own
-        alg_bytes4[3] = dq_literal ? dpole_quad_bytes(*scap) : 0.0;
+        P.alg_bytes[0] = latlon_strip_bytes(ll, 0, s1) + (launch_b ? 0.0 : mesh_bytes) + ((have_quad && qp.has_top) ? 8.0 * ni : 0.0);   // + dxq[ny]
+        P.alg_bytes[1] = launch_b ? latlon_strip_bytes(ll, s1, n_strips_ll) + bq_bytes + mesh_bytes + (have_dp ? dpole_mesh_bytes(*scap) : 0.0) +
+                                        ((have_dquad && !dq_literal) ? dpole_quad_bytes(*scap) : 0.0)
+                                  : 0.0;
+        P.alg_bytes[2] = 0.0;   // the tail rewrites cells launch B has written: no bytes of its own
+        P.alg_bytes[3] = dq_literal ? dpole_quad_bytes(*scap) : 0.0;
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap && !have_dp);
-    const long na = A.share.n_wg + A.n_tab + A.n_dq_tab + A.n_dm_reset + A.n_mesh;
-    if (int e = mark(0)) return e;
-    if (na > 0) {
-        pass_a_kernel<N><<<(unsigned)na, PASS_TX, 0, st>>>(A);
-        OGG_LAUNCH_CHECK();
-    }
-    if (int e = mark(1)) return e;
+    P.na = (unsigned)(A.share.n_wg + A.n_tab + A.n_dq_tab + A.n_dm_reset + A.n_mesh);
     if (launch_b) {
         // dispatch order of the compute roles.  A big launch (>= ~2 M quadrature cells: a whole 1/8 degree cap or half of it) puts the
         // quadrature strips first (long, issue-bound waves) and the meshes last -- their short workgroups fill the slots the draining
@@ -376,7 +384,30 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
             B.share.claims = qp.p.ll_claims;
             B.share.n_help = B.share.n_wg * helpers;
         }
-        const unsigned nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad + B.share.n_help);
+        P.nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad + B.share.n_help);
+    }
+    P.nd = dq_literal ? (unsigned)(dq.gx * dq.n_chunks) : 0u;
+    P.have_quad = have_quad, P.dq_literal = dq_literal, P.launch_b = launch_b;
+    return OGG_OK;
+}
+
+template <int N>
+int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStream_t st) {
+    // ev: NULL, or 5 events (entries may be NULL) recorded before launch A and after launches A, B, C and D (bench.py times the
+    // launches with them)
+    auto mark = [&](int k) -> int {
+        if (ev && ev[k]) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
+        return OGG_OK;
+    };
+    if (alg_bytes4)
+        for (int k = 0; k < 4; ++k) alg_bytes4[k] = P.alg_bytes[k];
+    if (int e = mark(0)) return e;
+    if (P.na > 0) {
+        pass_a_kernel<N><<<P.na, PASS_TX, 0, st>>>(P.A);
+        OGG_LAUNCH_CHECK();
+    }
+    if (int e = mark(1)) return e;
+    if (P.launch_b) {
 #ifdef OGG_PASS_TIMELINE
         {
             unsigned long long mn[8], mx[8];
@@ -385,7 +416,7 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
             OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_max), mx, sizeof(mx)));
         }
 #endif
-        pass_b_kernel<N><<<nb, PASS_TX, 0, st>>>(B);
+        pass_b_kernel<N><<<P.nb, PASS_TX, 0, st>>>(P.B);
         OGG_LAUNCH_CHECK();
 #ifdef OGG_PASS_TIMELINE
         if (getenv("OGG_TIMELINE")) {
@@ -400,12 +431,11 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
 #endif
     }
     if (int e = mark(2)) return e;
-    if (have_quad) {
-        if (int e = launch_quad_tail<N>(qp, st)) return e;
+    if (P.have_quad) {
+        if (int e = launch_quad_tail<N>(P.qp, st)) return e;
     }
     if (int e = mark(3)) return e;
-    if (dq_literal) {
-        const unsigned nd = (unsigned)(dq.gx * dq.n_chunks);
+    if (P.dq_literal) {
 #ifdef OGG_DQ_PROFILE
         {
             unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -414,10 +444,10 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
             OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dq_prof_strip), z3, sizeof(z3)));
         }
 #endif
-        if (scap->order == 2)
-            pass_d_kernel<2><<<nd, PASS_TX, 0, st>>>(dq);
+        if (P.dq_order == 2)
+            pass_d_kernel<2><<<P.nd, PASS_TX, 0, st>>>(P.dq);
         else
-            pass_d_kernel<4><<<nd, PASS_TX, 0, st>>>(dq);
+            pass_d_kernel<4><<<P.nd, PASS_TX, 0, st>>>(P.dq);
         OGG_LAUNCH_CHECK();
 #ifdef OGG_DQ_PROFILE
         if (getenv("OGG_DQ_PROFILE")) {
@@ -439,16 +469,8 @@ int launch_pass(const FusedParams& ll, long ni1, int metrics, const ogg_bipolar_
     return mark(4);
 }
 
-}  // namespace
-
-extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows) {
-    if ((order != 2 && order != 4) || Ni <= 0 || n_pt_rows < 0) return 0;
-    return (long)((dm_workspace_bytes(Ni, n_pt_rows) + 255) / 256 * 256) + (long)dq_workspace_bytes(order, Ni, n_pt_rows);
-}
-
-extern "C" int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
-                                      const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** events5, double* alg_bytes4,
-                                      void* stream) {
+int build_pass_plan_any(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                        const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, PassPlan& P) {
     FusedParams ll;
     long points = 0;
     if (int e = plan_latlon(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, ll, points)) return e;
@@ -489,14 +511,63 @@ extern "C" int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlo
                         d.n_pt_rows, d.Nj);
         }
     }
+    switch (order) {
+        case 2: return build_pass_plan<2>(ll, ni1, metrics, cap, south_cap, P);
+        case 3: return build_pass_plan<3>(ll, ni1, metrics, cap, south_cap, P);
+        case 4: return build_pass_plan<4>(ll, ni1, metrics, cap, south_cap, P);
+        default: return build_pass_plan<5>(ll, ni1, metrics, cap, south_cap, P);
+    }
+}
+
+int run_pass_plan_any(const PassPlan& P, void** events5, double* alg_bytes4, void* stream) {
     hipStream_t st = ogg::as_stream(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(events5);
-    switch (order) {
-        case 2: return launch_pass<2>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
-        case 3: return launch_pass<3>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
-        case 4: return launch_pass<4>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
-        default: return launch_pass<5>(ll, ni1, metrics, cap, south_cap, ev, alg_bytes4, st);
+    switch (P.order) {
+        case 2: return run_pass_plan<2>(P, ev, alg_bytes4, st);
+        case 3: return run_pass_plan<3>(P, ev, alg_bytes4, st);
+        case 4: return run_pass_plan<4>(P, ev, alg_bytes4, st);
+        default: return run_pass_plan<5>(P, ev, alg_bytes4, st);
     }
+}
+
+}  // namespace
+
+extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows) {
+    if ((order != 2 && order != 4) || Ni <= 0 || n_pt_rows < 0) return 0;
+    return (long)((dm_workspace_bytes(Ni, n_pt_rows) + 255) / 256 * 256) + (long)dq_workspace_bytes(order, Ni, n_pt_rows);
+}
+
+// forward: ogg_dpole_band_workspace_bytes is used by the plan builder above
+extern "C" int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                                      const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** events5, double* alg_bytes4,
+                                      void* stream) {
+    PassPlan P;   // plan + run: the one-shot form
+    if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, south_cap, P)) return e;
+    return run_pass_plan_any(P, events5, alg_bytes4, stream);
+}
+
+extern "C" int ogg_supergrid_pass_plan_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                                           const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** plan_out) {
+    OGG_REQUIRE(plan_out, OGG_EARG, "ogg_supergrid_pass_plan: null plan_out");
+    *plan_out = nullptr;
+    PassPlan* P = new (std::nothrow) PassPlan;
+    OGG_REQUIRE(P, OGG_ENOMEM, "ogg_supergrid_pass_plan: out of host memory");
+    if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, south_cap, *P)) {
+        delete P;
+        return e;
+    }
+    *plan_out = P;
+    return OGG_OK;
+}
+
+extern "C" int ogg_supergrid_pass_run_dev(const void* plan, void** events5, double* alg_bytes4, void* stream) {
+    OGG_REQUIRE(plan, OGG_EARG, "ogg_supergrid_pass_run: null plan");
+    return run_pass_plan_any(*static_cast<const PassPlan*>(plan), events5, alg_bytes4, stream);
+}
+
+extern "C" int ogg_supergrid_pass_plan_destroy(void* plan) {
+    delete static_cast<PassPlan*>(plan);
+    return OGG_OK;
 }
 
 extern "C" int ogg_tripolar_pass_events_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re,

@@ -419,20 +419,38 @@ class Supergrid(object):
                     scap.dy = b["dy"].data_ptr() if b["n_cell"] else None
                     scap.area = b["area"].data_ptr() if b["n_cell"] else None
                     scap.workspace, scap.workspace_bytes = b["ws"].data_ptr(), b["ws_bytes"]
-            self._pass_args = (bands, arr, cap, scap)
-        bands, arr, cap, scap = self._pass_args
-        capref = ctypes.byref(cap) if cap is not None else None
-        scapref = ctypes.byref(scap) if scap is not None else None
+            # ... and so is the plan of the launches (kernel parameters, grid sizes, tiling knobs read from the environment NOW):
+            # a pass then costs the host one ctypes call and the launches
+            capref = ctypes.byref(cap) if cap is not None else None
+            scapref = ctypes.byref(scap) if scap is not None else None
+            handle = ctypes.c_void_p()
+            L.call("ogg_supergrid_pass_plan_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, scapref,
+                   ctypes.byref(handle))
+            self._pass_args = (bands, arr, cap, scap, handle)
+            self._pass_run = L.load().ogg_supergrid_pass_run_dev
+        handle = self._pass_args[4]
         if self.pass_events is None:
-            L.call("ogg_supergrid_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, scapref,
-                   None, None, st)
+            rc = self._pass_run(handle, None, None, st)
+            if rc:
+                L.check(rc)
             return
         # per-launch timing: five HIP events recorded by the library around its (up to) four launches
         evs = self._event_pool.pop() if self._event_pool else self._new_events()
         self.pass_bytes = (ctypes.c_double * 4)()
-        L.call("ogg_supergrid_pass_dev", len(bands), arr, p.Ni + 1, p.lon0, p.lenlon, p.Re, 0 if p.skip_metrics else 1, capref, scapref, evs,
-               self.pass_bytes, st)
+        L.call("ogg_supergrid_pass_run_dev", handle, evs, self.pass_bytes, st)
         self.pass_events.append(evs)
+
+    def replan(self):
+        """Drop the cached plan of the pass (rebuilt by the next pass: after a change of an OGG_* tiling knob in the environment)."""
+        if self._pass_args is not None:
+            L.call("ogg_supergrid_pass_plan_destroy", self._pass_args[4])
+            self._pass_args = None
+
+    def __del__(self):
+        try:
+            self.replan()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
 
     @staticmethod
     def _new_events():

@@ -270,7 +270,7 @@ def test_tripolar_pass_argument_errors(sg):
     plan = sg.SupergridPlan(1.0)
     g = sg.Supergrid(plan, device="cuda:0")
     g.step()
-    bands, arr, cap, _ = g._pass_args
+    bands, arr, cap = g._pass_args[:3]
     st = torch.cuda.current_stream().cuda_stream
     bad = L.BipolarBand.from_buffer_copy(cap)
     bad.order = 7
@@ -288,6 +288,26 @@ def test_tripolar_pass_argument_errors(sg):
     L.call("ogg_tripolar_pass_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, None, st)
     L.call("ogg_tripolar_pass_dev", 0, arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(cap), st)
     torch.cuda.synchronize()
+    # the two-step form: a plan is refused for the same reasons as the one-shot call, and a run needs a plan
+    handle = ctypes.c_void_p()
+    bad = L.BipolarBand.from_buffer_copy(cap)
+    bad.order = 7
+    with pytest.raises(Exception, match="Uncoded order"):
+        L.call("ogg_supergrid_pass_plan_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(bad), None, ctypes.byref(handle))
+    assert not handle.value
+    with pytest.raises(L.OggHipError, match="null plan"):
+        L.call("ogg_supergrid_pass_run_dev", None, None, None, st)
+    # plan once, run twice, against the one-shot call: the same bits
+    want = {f: g.buf["BP"][f].clone() for f in FIELDS}
+    for f in FIELDS:
+        g.buf["BP"][f].fill_(float("nan"))
+    L.call("ogg_supergrid_pass_plan_dev", len(bands), arr, plan.Ni + 1, plan.lon0, plan.lenlon, plan.Re, 1, ctypes.byref(cap), None, ctypes.byref(handle))
+    for _ in range(2):
+        L.call("ogg_supergrid_pass_run_dev", handle, None, None, st)
+    torch.cuda.synchronize()
+    L.call("ogg_supergrid_pass_plan_destroy", handle)
+    for f in FIELDS:
+        assert torch.equal(g.buf["BP"][f], want[f]), f
 
 
 def test_bench_json_contract(tmp_path):
