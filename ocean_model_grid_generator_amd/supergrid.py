@@ -37,18 +37,22 @@ def band(n_rows, rank, world):
     return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
 
 
-def band_weighted(cost, rank, world):
+def band_weighted(cost, rank, world, top_capacity=1.0):
     """Contiguous rows [lo, hi) of `rank` such that every rank gets about the same total cost; `cost` is the per-row
-    cost array.  The boundaries are a function of (cost, world) only, identical on every rank."""
+    cost array.  ``top_capacity``: the share of the LAST rank relative to the others' (it carries a fixed extra launch, the
+    literal fix-up of the bipolar quadrature, and so takes a smaller share of EVERY sub-grid: the lat-lon strips and the cap
+    workgroups of a rank finish together, so shortening one of them alone shortens nothing).  The boundaries are a function
+    of (cost, world, top_capacity) only, identical on every rank."""
     c = np.concatenate(([0.0], np.cumsum(np.asarray(cost, dtype=np.float64))))
     total = c[-1]
+    capacity = (world - 1) + top_capacity
 
     def edge(r):
         if r <= 0:
             return 0
         if r >= world:
             return len(cost)
-        return int(np.searchsorted(c, total * r / world, side="left"))
+        return int(np.searchsorted(c, total * r / capacity, side="left"))
 
     return edge(rank), edge(rank + 1)
 
@@ -142,17 +146,19 @@ class SupergridPlan(object):
                              rp=float(np.tan(0.5 * (90 - lat0_bp) * ogg.PI_180)))
             # Row cost for the band split of the cap, in units of a plain cell row.  The quadrature guards its algebraic per-point form
             # near the two pole points (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K))
-            # carry the guard (1.3x a plain row), and the band that holds the last row also runs the tail launch (literal fix-up of the
-            # guarded cells + the j = ny row), a fixed cost worth ~50 plain rows of the round-2 quadrature whatever the resolution.  These weights equalise the
-            # measured per-rank times of the fused pass at 1/8 and 1/16 degree over 2, 4 and 8 ranks (scripts/rank_sweep.py;
-            # OGG_BP_ROW_COST="fix,guard,lump" overrides them: weight of rows with fix-up cells, of guarded rows, lump on the last row).
+            # carry the guard (1.3x a plain row).  The band that holds the last row also runs the tail launch (literal fix-up of the
+            # guarded cells), a fixed cost of ~8 us whatever the resolution: that is taken off the last rank's share of EVERY sub-grid
+            # (rows_of: tail_us / pass_us below), not off its cap rows alone -- a rank's lat-lon strips and cap workgroups end together
+            # (timeline of launch B at 1/8 of the 1/8 degree grid: strips 35 us, quadrature 39 us), so a smaller cap share alone left the
+            # last rank as slow as before.  (scripts/rank_sweep.py; OGG_BP_ROW_COST="fix,guard,lump" overrides the row weights: rows with
+            # fix-up cells, guarded rows, a lump on the last row; OGG_TOP_RANK_TAIL_US the tail time.)
             import os
             K = float(os.environ.get("OGG_BP_GUARD_K", "4000"))
             if K > 4.0:
                 lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
                 guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
                 fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
-                w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,50").split(",")]
+                w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,0").split(",")]
                 w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
                 bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
                 bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
@@ -202,6 +208,13 @@ class SupergridPlan(object):
         self.Nj_scap = Nj_scap
         self.lat0_SO, self.latUp_SO = lat0_SO, latUp_SO
         self.subs = [s for s in (sc, so, merc, bp) if s is not None]  # south -> north
+        if bp is not None and not skip_metrics:
+            # the last rank's fix-up launch against a single-GPU pass of this grid (1.08e11 cells/s measured at 1/8 degree): see rows_of
+            import os
+            tail_us = float(os.environ.get("OGG_TOP_RANK_TAIL_US", "8"))
+            cells = sum(s.nj1 - 1 for s in self.subs) * Ni
+            for s in self.subs:
+                s.tail_us, s.pass_us = tail_us, cells / 1.08e5
         # Rows that --south_cutoff_row / _ang remove from the stitched grid (OGG:1268-1313) are not generated when the cut is known from the
         # sizes alone -- by row always; by angle on a regular cap, whose latitudes are an axis formula -- just as the doughnut rows are not
         # (OM4: 82 of the displaced-pole cap's 143 kept rows).  The cut of a displaced-pole cap by ANGLE needs the cap's latitudes and is
@@ -336,9 +349,17 @@ class Supergrid(object):
 
     @staticmethod
     def rows_of(s, rank, world):
-        """Point rows [lo, hi) of sub-grid `s` owned by `rank`: equal row counts, or equal cost where rows differ in cost."""
+        """Point rows [lo, hi) of sub-grid `s` owned by `rank`: equal row counts, or equal cost where rows differ in cost; the
+        last rank's share of every sub-grid is smaller by what the fix-up launch costs it (SubGridPlan.tail_us / pass_us, set by
+        SupergridPlan when the grid has a bipolar cap with metrics)."""
         cost = getattr(s, "row_cost", None)
-        return band_weighted(cost, rank, world) if cost is not None else band(s.nj1, rank, world)
+        tail_us, pass_us = getattr(s, "tail_us", 0.0), getattr(s, "pass_us", 0.0)
+        cap = 1.0
+        if world > 1 and tail_us > 0.0 and pass_us > 0.0:
+            cap = min(1.0, max(0.3, 1.0 - world * tail_us / pass_us))
+        if cost is None and cap == 1.0:
+            return band(s.nj1, rank, world)
+        return band_weighted(np.ones(s.nj1) if cost is None else cost, rank, world, cap)
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def _stream(self):
