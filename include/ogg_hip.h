@@ -260,9 +260,14 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
  * arc_form selects how the great-arc distance between two probes of the finite-difference stencil is taken:
  *   OGG_DP_ARC_LITERAL  the reference's arithmetic (haversine of the projected, unwrapped longitudes and latitudes,
  *                       OGG:522-532); the default of every entry point without an arc_form argument;
- *   OGG_DP_ARC_CHORD    same stencil, distance from the gnomonic images of the probes (no atan2 / unwrap): ~7x less arithmetic,
- *                       ~1.6e-9 relative from the reference's value (the reference's own rounding error there is ~2e-9), against
- *                       ~1e-10 for the literal form.  Opt-in only. */
+ *   OGG_DP_ARC_CHORD    same stencil, distance from the gnomonic images of the probes (no atan2 / unwrap): ~7x less arithmetic.
+ *                       NOT the reference's arithmetic; opt-in only.
+ * Measured against the CPU oracle at full 1/8 degree size (5760 x 560 cap, profiles/dp_parity.json; max relative difference of
+ * dx / dy / area): literal 1.3e-9 / 1.2e-9 / 7.6e-10, chord 1.5e-9 / 1.3e-9 / 9.8e-10 -- practically the same, and growing with the
+ * resolution for both (7e-12 at Ni = 72): the reference differentiates an arc of 2e-3 index units numerically, so ONE ulp of
+ * difference between the device library's atan2 and the host's is amplified by ~Ni / (4e-3 pi).  The literal form is the
+ * reference's operation sequence; it is not bit-identical to a CPU run because the transcendental functions are not (the
+ * restatements of atan / atan2 used here reproduce the bits of the ROCm 7.2 device library, ogg_libm_check_dev). */
 /* (OGG_DP_ARC_LITERAL = 0, OGG_DP_ARC_CHORD = 1: defined next to the error codes at the top of this file) */
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                         double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
@@ -330,7 +335,8 @@ int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream);
  * ogg_bipolar_dev.h): which = 0: asin on [0, 1] (x); 1: atan (x, any); 2: atan2(y, x), finite; 3: 1.0 / x and 4: sqrt(x) without
  * scaling and special cases, 2^-700 <= x <= 2^700; 5: y / x without scaling, 2^-300 <= |x|, |y| <= 2^300 or y = +-0; 6: atan (x) and
  * 7: atan2(y, x) with their coefficients in vector registers (the literal displaced-pole quadrature's forms); 8: atan2(y, x) with its
- * quotient taken without scaling (finite arguments, the larger one within 2^-300 .. 2^300).  The number of k < n for which the
+ * quotient taken without scaling (finite arguments, the larger one within 2^-300 .. 2^300); 9: atan2(y, x) for ANY arguments, infinities
+ * and NaNs included (the generic stencil kernel's form; two NaNs count as equal).  The number of k < n for which the
  * restatement differs IN ANY BIT from the library's own function is ADDED to *n_diff (device memory, 8 bytes, zeroed by the caller). */
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream);
 /* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:

@@ -30,6 +30,8 @@ int set_error(int code, const char* fmt, ...) {
 namespace {
 
 constexpr size_t kStageBytes = 8u << 20;
+constexpr size_t kArenaKeepBytes = 64u << 20;   // a call's device scratch above this is returned to the device when the call ends
+constexpr int kMaxDevices = 64;
 
 struct Staging {
     std::mutex mu;
@@ -48,50 +50,63 @@ struct Staging {
         }
         return OGG_OK;
     }
+    size_t hint = 0;                                // what the last call took in all (capped): the size of the next first block
     int take(void** out, size_t bytes) {
         bytes = (bytes + 255) & ~size_t(255);
         if (blocks.empty() || used + bytes > blocks.back().second) {
-            size_t total = bytes;
-            for (auto& b : blocks) total += b.second;
+            // a new block for THIS request (never the sum of the earlier ones: those stay where they are until the call ends);
+            // the first block of a call is as large as the whole previous call, so a repeated call allocates nothing
+            const size_t want = blocks.empty() && hint > bytes ? hint : bytes;
             void* p = nullptr;
-            hipError_t e = hipMalloc(&p, total);
+            hipError_t e = hipMalloc(&p, want);
             if (e != hipSuccess) {
                 const int code = (e == hipErrorOutOfMemory) ? OGG_ENOMEM : OGG_EHIP;
-                return set_error(code, "hipMalloc(%zu bytes) failed: %s", total, hipGetErrorString(e));
+                return set_error(code, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
             }
-            blocks.emplace_back(static_cast<char*>(p), total);
+            blocks.emplace_back(static_cast<char*>(p), want);
             used = 0;
         }
         *out = blocks.back().first + used;
         used += bytes;
         return OGG_OK;
     }
-    void release() {   // end of a call: keep the largest block (it holds the sum of all earlier ones), free the rest
-        while (blocks.size() > 1) {
-            (void)hipFree(blocks.front().first);
-            blocks.erase(blocks.begin());
+    void release() {   // end of a call (the stream has been synchronised): keep ONE block of at most kArenaKeepBytes
+        size_t total = 0;
+        for (auto& b : blocks) total += b.second;
+        if (blocks.size() > 1 || total > kArenaKeepBytes) {
+            for (auto& b : blocks) (void)hipFree(b.first);
+            blocks.clear();
+            hint = total < kArenaKeepBytes ? total : kArenaKeepBytes;
         }
         used = 0;
     }
 };
 
-Staging g_staging;
+// one staging state per DEVICE: stream, pinned buffers and arena belong to the device that was current when they were created, and a
+// caller may move on to another one (ogg_set_device / hipSetDevice / torch.cuda.set_device) between calls
+Staging g_staging_of[kMaxDevices];
+
+Staging& staging_of_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return g_staging_of[dev];
+}
 
 }  // namespace
 
 // scratch device buffers and transfers of one host-pointer call
 class DevScratch {
    public:
-    DevScratch() : lock_(g_staging.mu) {}
+    DevScratch() : st_(staging_of_current_device()), lock_(st_.mu) {}
     ~DevScratch() {
-        if (g_staging.stream) (void)hipStreamSynchronize(g_staging.stream);
-        g_staging.release();
+        if (st_.stream) (void)hipStreamSynchronize(st_.stream);
+        st_.release();
     }
-    void* stream() { return g_staging.stream; }
+    void* stream() { return st_.stream; }
     int alloc(double** out, long n) {
-        if (int e = g_staging.init()) return e;
+        if (int e = st_.init()) return e;
         void* p = nullptr;
-        if (int e = g_staging.take(&p, (size_t)(n > 0 ? n : 1) * sizeof(double))) return e;
+        if (int e = st_.take(&p, (size_t)(n > 0 ? n : 1) * sizeof(double))) return e;
         *out = static_cast<double*>(p);
         return OGG_OK;
     }
@@ -103,10 +118,10 @@ class DevScratch {
         int k = 0;
         for (size_t off = 0; off < bytes; off += kStageBytes, k ^= 1) {
             const size_t len = bytes - off < kStageBytes ? bytes - off : kStageBytes;
-            OGG_HIP_CHECK(hipEventSynchronize(g_staging.done[k]));   // the copy that last read this buffer has finished
-            memcpy(g_staging.pinned[k], src + off, len);
-            OGG_HIP_CHECK(hipMemcpyAsync(dst + off, g_staging.pinned[k], len, hipMemcpyHostToDevice, g_staging.stream));
-            OGG_HIP_CHECK(hipEventRecord(g_staging.done[k], g_staging.stream));
+            OGG_HIP_CHECK(hipEventSynchronize(st_.done[k]));   // the copy that last read this buffer has finished
+            memcpy(st_.pinned[k], src + off, len);
+            OGG_HIP_CHECK(hipMemcpyAsync(dst + off, st_.pinned[k], len, hipMemcpyHostToDevice, st_.stream));
+            OGG_HIP_CHECK(hipEventRecord(st_.done[k], st_.stream));
         }
         return OGG_OK;
     }
@@ -120,17 +135,17 @@ class DevScratch {
         for (size_t off = 0; off < bytes; off += kStageBytes, k ^= 1) {
             const size_t len = bytes - off < kStageBytes ? bytes - off : kStageBytes;
             if (pending_len[k]) {   // drain the chunk that sits in this buffer before the engine overwrites it
-                OGG_HIP_CHECK(hipEventSynchronize(g_staging.done[k]));
-                memcpy(dst + pending_off[k], g_staging.pinned[k], pending_len[k]);
+                OGG_HIP_CHECK(hipEventSynchronize(st_.done[k]));
+                memcpy(dst + pending_off[k], st_.pinned[k], pending_len[k]);
             }
-            OGG_HIP_CHECK(hipMemcpyAsync(g_staging.pinned[k], src + off, len, hipMemcpyDeviceToHost, g_staging.stream));
-            OGG_HIP_CHECK(hipEventRecord(g_staging.done[k], g_staging.stream));
+            OGG_HIP_CHECK(hipMemcpyAsync(st_.pinned[k], src + off, len, hipMemcpyDeviceToHost, st_.stream));
+            OGG_HIP_CHECK(hipEventRecord(st_.done[k], st_.stream));
             pending_off[k] = off, pending_len[k] = len;
         }
         for (int j = 0; j < 2; ++j, k ^= 1) {   // oldest first
             if (pending_len[k]) {
-                OGG_HIP_CHECK(hipEventSynchronize(g_staging.done[k]));
-                memcpy(dst + pending_off[k], g_staging.pinned[k], pending_len[k]);
+                OGG_HIP_CHECK(hipEventSynchronize(st_.done[k]));
+                memcpy(dst + pending_off[k], st_.pinned[k], pending_len[k]);
                 pending_len[k] = 0;
             }
         }
@@ -138,6 +153,7 @@ class DevScratch {
     }
 
    private:
+    Staging& st_;                        // (declared before lock_: the lock is taken on this device's mutex)
     std::lock_guard<std::mutex> lock_;
 };
 

@@ -31,9 +31,12 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
             else
                 a = atan2_lib(y[k], x[k], c), b = atan2(y[k], x[k]);
             c.keep();
-        } else {                              // which == 8: atan2 with the quotient taken without scaling, literal coefficients
+        } else if (which == 8) {              // atan2 with the quotient taken without scaling, literal coefficients
             const AtanLiterals c;
             a = atan2_lib_normal(y[k], x[k], c), b = atan2(y[k], x[k]);
+        } else {                              // which == 9: atan2 for any arguments (infinities, NaNs)
+            a = atan2_lib_any(y[k], x[k]), b = atan2(y[k], x[k]);
+            if (a != a && b != b) b = a;      // any NaN is the same answer
         }
         diff = __double_as_longlong(a) != __double_as_longlong(b);
     }
@@ -45,7 +48,7 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
 extern "C" {
 
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream) {
-    OGG_REQUIRE(which >= 0 && which <= 8 && n >= 0 && x && n_diff && ((which != 2 && which != 5 && which != 7 && which != 8) || y), OGG_EARG,
+    OGG_REQUIRE(which >= 0 && which <= 9 && n >= 0 && x && n_diff && ((which != 2 && which != 5 && which != 7 && which != 8 && which != 9) || y), OGG_EARG,
                 "ogg_libm_check: bad argument");
     if (n == 0) return OGG_OK;
     libm_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(which, n, x, y, n_diff);

@@ -526,7 +526,8 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
 // accurate to 2e-9 (relative).  The chord form keeps the SAME stencil (the same probe points, the same conformal image w of
 // each probe) but takes the distance between two probes from their positions on the sphere -- from vectors pa, pb along the two
 // points: sin(ds) = |pa x pb| / (|pa| |pb|) -- : no atan2 / atan / hypot per probe, no sin/cos/asin per pair and no longitude at
-// all, hence no unwrap.  Its h is accurate to 8e-10 and differs from the reference's by ~1.6e-9, i.e. by less
+// all, hence no unwrap.  Its h is accurate to 8e-10 and differs from a CPU evaluation of the reference's by ~1.5e-9 at 1/8 degree (the
+// literal form: ~1.3e-9, profiles/dp_parity.json), i.e. by less
 // than the reference's own rounding error, but it is NOT the reference's arithmetic: it is an explicit option (arc_form = 1),
 // the literal form is the default everywhere.
 // A probe's point on the sphere in homogeneous form: with w = num / den the conformal image of the probe (OGG:454-455),

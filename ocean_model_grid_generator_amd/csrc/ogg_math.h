@@ -351,6 +351,17 @@ OGG_DEV double atan2_lib(double y, double x, const C& c) {   // finite arguments
     return copysign(a, y);
 }
 
+// atan2 for ANY arguments -- infinities and NaNs as the library answers them (both infinite: +-pi/4 or +-3pi/4; a NaN: NaN) -- for
+// kernels that take a caller's arrays (the generic stencil kernel behind ogg_angle_x / ogg_grid_metrics_midas): two more selects
+template <class C>
+OGG_DEV double atan2_lib_any(double y, double x, const C& c) {
+    double a = atan2_lib(y, x, c);
+    const bool xinf = fabs(x) == __builtin_inf(), yinf = fabs(y) == __builtin_inf();
+    const double q = (__double2hiint(x) < 0) ? 0x1.2d97c7f3321d2p+1 : 0x1.921fb54442d18p-1;   // 3 pi / 4, pi / 4
+    a = (xinf && yinf) ? copysign(q, y) : a;
+    return (x != x || y != y) ? __builtin_nan("") : a;
+}
+
 // one-shot forms (coefficients loaded for this one call)
 OGG_DEV double atan_lib(double x) {
     AtanCoefs c;
@@ -363,6 +374,13 @@ OGG_DEV double atan2_lib(double y, double x) {
     AtanCoefs c;
     c.load(kAtanRed);
     const double r = atan2_lib(y, x, c);
+    c.keep();
+    return r;
+}
+OGG_DEV double atan2_lib_any(double y, double x) {
+    AtanCoefs c;
+    c.load(kAtanRed);
+    const double r = atan2_lib_any(y, x, c);
     c.keep();
     return r;
 }

@@ -83,16 +83,16 @@ OGG_DEV double dx_of(const RowQ& q, double Re) {
     return Re * sqrt(q.dyi * q.dyi + t * t);
 }
 
-// OGG:725-728
+// OGG:725-728.  A caller's mesh may hold anything: the arctangent answers infinities and NaNs as the library's does (atan2_lib_any).
 OGG_DEV double angle_of(const RowVals& v, long i, long ni1) {
     const double c = cos(v.yc * kPi180);
     double a;
     if (i == 0)
-        a = atan2_lib(v.yr - v.yc, (v.xr - v.xc) * c);
+        a = atan2_lib_any(v.yr - v.yc, (v.xr - v.xc) * c);
     else if (i == ni1 - 1)
-        a = atan2_lib(v.yc - v.yl, (v.xc - v.xl) * c);
+        a = atan2_lib_any(v.yc - v.yl, (v.xc - v.xl) * c);
     else
-        a = atan2_lib(v.yr - v.yl, (v.xr - v.xl) * c);
+        a = atan2_lib_any(v.yr - v.yl, (v.xr - v.xl) * c);
     return div_pi180(a);
 }
 

@@ -23,6 +23,7 @@ import sys
 import numpy as np
 
 from . import _lib as L
+from .plotting import cut_above, cut_below, displacedPoleCap_plot, plot_mesh_in_latlon, plot_mesh_in_xyz  # noqa: F401  (OGG:604-679)
 
 # Constants (OGG:13-16)
 PI_180 = np.pi / 180.0
@@ -399,7 +400,8 @@ def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_d
     """OGG:565-601 (kernels dpole_quad_tables / dpole_quad_kernel: the lattice is evaluated and reduced on chip).
     ``arc_form`` (not in the reference): "literal" (default) follows the reference's great_arc_distance operation for
     operation; "chord" takes the same finite-difference stencil's distances from the probes' positions on the sphere --
-    ~7x less arithmetic, ~1.6e-9 relative from the reference's value instead of ~1e-10 (include/ogg_hip.h)."""
+    ~7x less arithmetic, not the reference's arithmetic.  Both are ~1.3e-9 relative from a CPU evaluation at 1/8 degree (one ulp of
+    atan2 amplified by the reference's own finite-difference stencil; include/ogg_hip.h, profiles/dp_parity.json)."""
     print("   Calculating displaced pole cap metrics via quadrature ...")
     nx, ny = int(nx), int(ny)
     form = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[arc_form]
@@ -673,7 +675,7 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
     nyp = g.stitched_rows(cut)
     print("shapes: ", (nyp, plan.Ni + 1), (nyp, plan.Ni + 1), (nyp, plan.Ni), (nyp - 1, plan.Ni + 1), (nyp - 1, plan.Ni), (nyp, plan.Ni + 1))
     out = None
-    if return_arrays or write_subgrid_files or debug:
+    if return_arrays or write_subgrid_files or debug or plotem:
         out = SG.stitch(plan, [g.bands_to_host()])
     if write_subgrid_files:
         for name, piece in out["sub"].items():
@@ -687,11 +689,29 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
                 chksum(out[lbl], lbl)
         g.write_nc(str(gridfilename), cut, description=desc, history=hist, source=source, no_changing_meta=no_changing_meta)
         print("Wrote the whole grid to file ", gridfilename)
-    if plotem:
-        print("   --plotem: plotting (matplotlib, OGG:604-679) is not part of this build; the flag is accepted and ignored")
+    if plotem:   # OGG:1230-1234, 1445-1447, from the stitched host arrays (raises if matplotlib is missing: never ignored silently)
+        _plot_grids(out, r_dp, lon_dp, lat_dp, plan.lon0, plan.lat0_SO, inverse_resolution, out["x"], out["y"])
     print("runtime(secs)  %s" % (time.time() - start_time))
     if return_arrays:
         return out
+
+
+def _plot_grids(out, r_dp, lon_dp, lat_dp, lon0, lat0_SC, refineR, x, y):
+    """--plotem (OGG:1230-1234, 1445-1447): the displaced-pole cap (with the Southern Ocean piece) on polar axes when there is one, then the
+    whole grid south of -40 and north of 40 degrees."""
+    sub = out.get("sub", {}) if isinstance(out, dict) else {}
+    if "SC" in sub and (r_dp != 0.0 or lat_dp > -90):
+        sc = sub["SC"]
+        ax = displacedPoleCap_plot(_sub_xy(sc)[0], _sub_xy(sc)[1], lon0, lon_dp, lat0_SC, stride=int(refineR * 10), block=True, dplat=lat_dp)
+        if "SO" in sub:
+            plot_mesh_in_latlon(_sub_xy(sub["SO"])[0], _sub_xy(sub["SO"])[1], stride=int(refineR * 10), newfig=False, axis=ax)
+    plot_mesh_in_xyz(x, y, stride=30, upperlat=-40, title="Grid south of -40 degrees")
+    plot_mesh_in_xyz(x, y, stride=30, lowerlat=40, title="Grid north of 40 degrees")
+
+
+def _sub_xy(piece):
+    """(x, y) of a sub-grid record: a dict of fields (pass path) or a tuple starting with x, y (function-level path)."""
+    return (piece["x"], piece["y"]) if isinstance(piece, dict) else (piece[0], piece[1])
 
 
 def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=None,
@@ -952,7 +972,7 @@ def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=
                  source=source, no_changing_meta=no_changing_meta, debug=debug)
         print("Wrote the whole grid to file ", gridfilename)
     if plotem:
-        print("   --plotem: plotting (matplotlib, OGG:604-679) is not part of this build; the flag is accepted and ignored")
+        _plot_grids({"sub": sub}, r_dp, lon_dp, lat_dp, lon0, lat0_SO, inverse_resolution, x3, y3)
     print("runtime(secs)  %s" % (time.time() - start_time))
     if return_arrays:
         return {"x": x3, "y": y3, "dx": dx3, "dy": dy3, "area": area3, "angle_dx": angle3, "sub": sub}

@@ -240,7 +240,7 @@ def test_supergrid_pass_southern_cap_alone_matches_function_level(hip, order, ar
     want = orc.displacedPoleCap_metrics_quad(order, Ni, Nj, geo[0], geo[1], geo[2], geo[3])
     for f, w in zip(("dx", "dy", "area"), want):
         w = w[j0:j0 + n]
-        assert np.abs(a[f].cpu().numpy() - w).max() <= 1e-9 * np.abs(w).max(), (order, arc, f)
+        assert np.abs(a[f].cpu().numpy() - w).max() <= 2e-12 * Ni * np.abs(w).max(), (order, arc, f)   # dp_quad_rel_tol(Ni) = 4e-10
 
 
 def test_tripolar_pass_full_size_r8_bitwise(sg):
@@ -572,13 +572,14 @@ def test_full_size_r8_pass_vs_oracle(sg):
     assert rep["x_max"] < 2e-11 and rep["x_frac_gt_1e12"] < 1e-5                # next to the cap's symmetry meridians only
     # dx, dy of the lat-lon sub-grids are differences of coordinates that themselves differ by ~1e-14 degrees (ocml vs the host
     # libm in atan(sinh)): 1e-14 deg x 111 km/deg = 1e-9 m on a 7 km cell; area likewise (one ulp of sin moves it by 3e-5 m^2)
-    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (1e-3, 5e-12))):
+    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (0.0, 1.2e-11))):
         d = np.abs(got[f] - want[f])
         rep[f + "_max_abs"] = float(d.max())
         rep[f + "_max_rel"] = float((d / np.maximum(np.abs(want[f]), 1e-300))[want[f] != 0].max())
     record("full_r8_pass_vs_oracle", **rep)
-    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (1e-3, 5e-12))):
+    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (0.0, 1.2e-11))):   # area: 10 x the measured 1.2e-12 / 9.8e-6 m^2
         assert np.all(np.abs(got[f] - want[f]) <= a + r * np.abs(want[f])), (f, rep)
+    assert rep["area_max_abs"] < 1e-4, rep
     d = np.abs(got["angle_dx"] - want["angle_dx"])
     d = np.minimum(d, np.abs(d - 360.0))
     rep["angle_p999"] = float(np.quantile(d, 0.999))
