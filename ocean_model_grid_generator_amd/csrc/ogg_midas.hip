@@ -12,7 +12,10 @@ namespace {
 
 using namespace ogg;
 
-constexpr int MIDAS_TX = 256;   // columns per workgroup (4 waves)
+#ifndef OGG_MIDAS_TX
+#define OGG_MIDAS_TX 256
+#endif
+constexpr int MIDAS_TX = OGG_MIDAS_TX;   // columns per workgroup (4 waves)
 constexpr int MIDAS_ROWS = 16;  // maximum point rows per workgroup; small bands use fewer (grid >= ~2000 workgroups)
 
 struct MidasParams {

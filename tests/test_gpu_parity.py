@@ -356,6 +356,28 @@ def test_division_without_scaling_and_vector_register_arctangents_equal_the_libr
     assert _libm_check(9, x2, y2) == 0
 
 
+def test_sin_cos_restatements_equal_the_library(hip):
+    """cos_lib / sincos_lib (ogg_math.h: the library's reduction and kernels with every constant a scalar operand) against cos / sincos:
+    every bit, 4e7 arguments -- latitudes in radians (what the stencil kernel feeds them), arguments up to 2^30 in both signs, multiples of
+    pi/2 and their neighbours, tiny values, and what goes to the library's own large-argument path (>= 2^30, infinities, NaN)."""
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(15)
+    n = 40_000_000
+    x = (torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) * 2 - 1) * (np.pi / 2)            # latitudes
+    q = n // 4
+    m = torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) + 1.0
+    e = torch.randint(-60, 30, (q,), device="cuda:0", generator=g).to(torch.int32)
+    sgn = torch.randint(0, 2, (q,), device="cuda:0", generator=g).to(torch.float64) * 2 - 1
+    x[:q] = sgn * torch.ldexp(m, e)                                                                        # 2^-60 .. 2^30
+    k = torch.randint(-2000, 2000, (q,), device="cuda:0", generator=g).to(torch.float64)
+    x[q: 2 * q] = k * (np.pi / 2) + (torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) - 0.5) * 1e-9   # next to multiples of pi/2
+    sp = torch.tensor([0.0, -0.0, 5e-324, -5e-324, np.pi / 2, -np.pi / 2, np.pi, 2.0 ** 30, -(2.0 ** 30), np.nextafter(2.0 ** 30, 0), 1e300,
+                       float("inf"), float("-inf"), float("nan")], dtype=torch.float64, device="cuda:0")
+    x[-sp.numel():] = sp
+    for which in (10, 11, 12):
+        assert _libm_check(which, x) == 0, which
+
+
 def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
     got = []
     for rows in ("8", "1", "5", "32"):
