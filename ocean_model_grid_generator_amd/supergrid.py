@@ -213,8 +213,11 @@ class SupergridPlan(object):
             import os
             tail_us = float(os.environ.get("OGG_TOP_RANK_TAIL_US", "8"))
             cells = sum(s.nj1 - 1 for s in self.subs) * Ni
+            pass_us = cells / 1.08e5
+            if sc is not None and sc.kind == "dpole":   # + the displaced-pole quadrature: 0.66 ns per cell literal (launch D), 0.10 ns chord
+                pass_us += (sc.nj1 - 1) * Ni * (6.6e-4 if self.dp_arc == L.DP_ARC_LITERAL else 1.0e-4)
             for s in self.subs:
-                s.tail_us, s.pass_us = tail_us, cells / 1.08e5
+                s.tail_us, s.pass_us = tail_us, pass_us
         # Rows that --south_cutoff_row / _ang remove from the stitched grid (OGG:1268-1313) are not generated when the cut is known from the
         # sizes alone -- by row always; by angle on a regular cap, whose latitudes are an axis formula -- just as the doughnut rows are not
         # (OM4: 82 of the displaced-pole cap's 143 kept rows).  The cut of a displaced-pole cap by ANGLE needs the cap's latitudes and is
