@@ -498,10 +498,27 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
     p.n_rows = M * n_cell_rows + 1, p.n_cols = M * g.ni + 1;
     p.n_strips = dq_strips(order, g.ni);
     p.gx = (p.n_strips + DQ_WAVES - 1) / DQ_WAVES;
-    // enough waves to fill 1024 SIMDs several times over without recomputing more than a few % of the lattice rows
-    long target = 8192;
-    if (const char* ev = getenv("OGG_DPQUAD_TARGET_WAVES")) target = atol(ev) > 0 ? atol(ev) : target;
-    long rpc = (n_cell_rows * p.n_strips + target - 1) / target;
+    // Cell rows per chunk.  A wave walks M rpc + 1 lattice rows (the first one recomputed), and the launch runs in ROUNDS of as many
+    // waves as the chip holds: the literal form, at 2 waves per SIMD, 2048 -- so the time goes as rounds x lattice rows per wave, and the
+    // rpc that minimises it is taken (OM4's cap, 61 x 183 strips: rpc 6 = 2013 waves = ONE round, 0.152 ms; the old "8192 waves" rule
+    // chose rpc 2 = 5673 waves = 2.8 rounds, 0.175 ms; the 1/8 degree cap keeps its rpc 13 = 3.9 rounds).  The chord form shares launch B
+    // with other roles and keeps the wave-count rule.  OGG_DPQUAD_TARGET_WAVES forces that rule with another count (experiments, tests).
+    long rpc;
+    const char* ev = getenv("OGG_DPQUAD_TARGET_WAVES");
+    if (arc_form == DP_ARC_LITERAL && !(ev && atol(ev) > 0)) {
+        const long slots = 2048;
+        long best_cost = -1;
+        rpc = 1;
+        for (long r = 1; r <= DQ_RPC_MAX; ++r) {
+            const long waves = ((n_cell_rows > 0 ? n_cell_rows : 1) + r - 1) / r * p.n_strips;
+            const long cost = (waves + slots - 1) / slots * (M * r + 1);
+            if (best_cost < 0 || cost < best_cost) best_cost = cost, rpc = r;
+        }
+    } else {
+        long target = 8192;   // enough waves to fill 1024 SIMDs several times over without recomputing more than a few % of the lattice rows
+        if (ev) target = atol(ev) > 0 ? atol(ev) : target;
+        rpc = (n_cell_rows * p.n_strips + target - 1) / target;
+    }
     p.rows_per_chunk = rpc < 1 ? 1 : (rpc > DQ_RPC_MAX ? DQ_RPC_MAX : rpc);
     OGG_REQUIRE((size_t)ws_bytes >= 16 + (size_t)(NV * (p.n_rows + 2 * p.n_cols)) * sizeof(double) +
                                         (arc_form == DP_ARC_LITERAL ? (size_t)(((n_cell_rows > 0 ? n_cell_rows : 1) + p.rows_per_chunk - 1) / p.rows_per_chunk *
