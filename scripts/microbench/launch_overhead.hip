@@ -16,6 +16,16 @@ __global__ void chain_kernel(double* out, int n, double a) {
     if (x == 123.456) out[0] = x;
 }
 
+struct Big {   // the size of the pass kernels' parameter blocks (1.6-2 KB)
+    double v[240];
+};
+__global__ void empty_big_kernel(Big b, double* out) {
+    if (out && threadIdx.x == 1024) out[0] = b.v[7];
+}
+__global__ void empty_ptr_kernel(const Big* b, double* out) {
+    if (out && threadIdx.x == 1024) out[0] = b->v[7];
+}
+
 template <class F>
 double per_launch_us(F launch, int reps) {
     for (int k = 0; k < 50; ++k) launch();
@@ -37,6 +47,15 @@ int main() {
     for (int n : {100, 500, 1000, 2000, 4000})
         printf("chain of %4d dependent fp64 fma, 106 workgroups of 256: %.2f us per launch\n", n,
                per_launch_us([&] { chain_kernel<<<106, 256, 0, st>>>(d, n, 0.999999); }, reps));
+    {   // does the size of the kernel-argument block matter?  1.9 KB by value against a pointer to the same block in device memory
+        Big hb{};
+        Big* db;
+        hipMalloc(&db, sizeof(Big));
+        hipMemcpy(db, &hb, sizeof(Big), hipMemcpyHostToDevice);
+        for (int wg : {106, 1400})
+            printf("empty kernel, %5d workgroups, 1920-byte argument block by value: %.2f us per launch; by pointer: %.2f us\n", wg,
+                   per_launch_us([&] { empty_big_kernel<<<wg, 256, 0, st>>>(hb, d); }, reps), per_launch_us([&] { empty_ptr_kernel<<<wg, 256, 0, st>>>(db, d); }, reps));
+    }
     // three launches per "pass" against one
     printf("3 x empty(106): %.2f us per triple\n", per_launch_us([&] { for (int k = 0; k < 3; ++k) empty_kernel<<<106, 256, 0, st>>>(d); }, reps));
     hipEvent_t e0, e1;

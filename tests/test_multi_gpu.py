@@ -71,3 +71,25 @@ def test_checksum_is_independent_of_the_pipeline():
     assert p.returncode == 0, p.stderr[-3000:]
     c = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert c["field_checksums"] == a["field_checksums"] and c["world_size"] == 1 and c["per_rank"][0]["rank"] == 0
+
+
+def test_host_pointer_layer_follows_the_current_device():
+    """The staging state of the host-pointer functions (stream, pinned buffers, device arena) is kept PER DEVICE: after
+    ogg_set_device(1) a host-pointer call must run on device 1 and give device 0's bits.  In a child process (it changes the current
+    device); needs >= 2 visible GPUs."""
+    if _gpus() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    code = (
+        "import numpy as np\n"
+        "from ocean_model_grid_generator_amd import _lib as L, ocean_grid_generator as ogg\n"
+        "a = ogg.bipolar_cap_metrics_quad_fast(5, 360, 60, 64.9, -300.0, 0.22)\n"
+        "L.call('ogg_set_device', 1)\n"
+        "b = ogg.bipolar_cap_metrics_quad_fast(5, 360, 60, 64.9, -300.0, 0.22)\n"
+        "c = ogg.displacedPoleCap_metrics_quad(4, 360, 40, -300.0, -78.0, 80.0, 0.2)\n"
+        "L.call('ogg_set_device', 0)\n"
+        "d = ogg.displacedPoleCap_metrics_quad(4, 360, 40, -300.0, -78.0, 80.0, 0.2)\n"
+        "assert all(np.array_equal(x, y) for x, y in zip(a, b)) and all(np.array_equal(x, y) for x, y in zip(c, d))\n"
+        "print('ok')\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-3000:]
