@@ -588,6 +588,52 @@ def test_full_size_r8_pass_vs_oracle(sg):
     record("full_r8_pass_vs_oracle", **rep)
 
 
+def test_full_size_r16_pass_vs_oracle(sg):
+    """BASELINE config 5 (1/16 degree, 101 M cells, 4.9 GB of fields) through the fused pass against the numpy oracle, every field,
+    every element (the oracle needs about a minute and ~15 GB on the host).  The bounds of the 1/8 degree test, except where the
+    resolution enters: the MIDAS area of a lat-lon cell is 4x smaller and its one-ulp-of-sin noise with it (measured 7.4e-6 m^2), the
+    cells at the cap's two pole points reach 6e-14 relative in area with every cell literal (test_bipolar_quad_full_size_r16_by_zone)."""
+    import gc
+    import torch
+    from test_gpu_parity import record
+    plan = sg.SupergridPlan(16.0)
+    g = sg.Supergrid(plan, device="cuda:0")
+    assert g.launch == "pass"
+    g.step()
+    torch.cuda.synchronize()
+    got = sg.stitch(plan, [g.bands_to_host()])
+    got.pop("sub", None)
+    del g
+    gc.collect()
+    want = orc.make_supergrid(16.0, skip_doughnut_rows=True)
+    want.pop("sub", None)
+    rep = {}
+    for f in FIELDS:
+        assert got[f].shape == want[f].shape == ((8785 if f in ("x", "y", "dx", "angle_dx") else 8784), (11521 if f in ("x", "y", "dy", "angle_dx") else 11520)), f
+    d = np.abs(got["y"] - want["y"])
+    rep["y_max"] = float(d.max())
+    rep["y_max_excl_bp_poles"] = float(np.sort(d[-3:].ravel())[-5]) if d[:-3].max() < 1e-12 else float(d[:-3].max())
+    assert d[:-3].max() < 1e-12 and rep["y_max_excl_bp_poles"] < 1e-12 and rep["y_max"] < 1e-6
+    d = np.abs(got["x"] - want["x"])
+    rep["x_max"] = float(d.max())
+    rep["x_frac_gt_1e12"] = float(np.mean(d > 1e-12))
+    assert rep["x_max"] < 2e-11 and rep["x_frac_gt_1e12"] < 1e-5
+    for f, (a, r) in (("dx", (2e-8, 5e-14)), ("dy", (2e-8, 5e-14)), ("area", (0.0, 1.2e-11))):
+        d = np.abs(got[f] - want[f])
+        rep[f + "_max_abs"] = float(d.max())
+        nz = want[f] != 0
+        rep[f + "_max_rel"] = float((d[nz] / np.abs(want[f][nz])).max())
+        assert np.all(d <= a + r * np.abs(want[f])), (f, rep)
+        del d, nz
+    assert rep["area_max_abs"] < 1e-4, rep
+    d = np.abs(got["angle_dx"] - want["angle_dx"])
+    d = np.minimum(d, np.abs(d - 360.0))
+    rep["angle_p999"] = float(np.quantile(d, 0.999))
+    rep["angle_frac_gt_1e9"] = float(np.mean(d > 1e-9))
+    assert rep["angle_p999"] < 1e-10 and rep["angle_frac_gt_1e9"] < 1e-5
+    record("full_r16_pass_vs_oracle", **rep)
+
+
 def test_full_size_r8_latdp_pass_vs_oracle(sg):
     """BASELINE config 4 (1/8 degree with the displaced south pole, --lat_dp -85.85) at full size against the oracle (the
     oracle needs ~40 s for the cap's finite-difference quadrature), in BOTH arc forms of the cap's quadrature.  The differences
