@@ -349,11 +349,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    # OGG_BENCH_ONE_GPU=1: a REHEARSAL of the N-rank run on a box with one GPU -- every rank on cuda:0, the collectives over gloo (RCCL
+    # does not put two ranks on one device).  Everything else is the N-GPU run: the launcher, the bands of each rank, the barriers,
+    # the reductions, the gathered per-rank lines.  The output says so ("rehearsal"); its times are those of N processes sharing a card.
+    rehearsal = world > 1 and bool(os.environ.get("OGG_BENCH_ONE_GPU"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     use_dist = world > 1 or bool(os.environ.get("OGG_FORCE_DIST"))   # OGG_FORCE_DIST: exercise the RCCL calls at world size 1
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     from ocean_model_grid_generator_amd import _lib, supergrid
 
@@ -440,7 +449,7 @@ def main():
         sg.pass_events = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        supergrid.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # self-check, untimed: the reference's CHECK_metrics numbers (OGG:732-770) for the bands now in HBM -- five sums per band on the
     # device and one all-reduce (RCCL) of n_subs x 7 doubles, the only collective of the default pipeline
@@ -464,7 +473,7 @@ def main():
                     if t.numel():
                         cs[a, c] = t.contiguous().view(torch.int64).sum()
             if use_dist:
-                dist.all_reduce(cs)
+                supergrid.all_reduce(cs)
             checksums = {s_.name: {f: "%016x" % (int(cs[a, c].item()) & 0xFFFFFFFFFFFFFFFF) for c, f in enumerate(supergrid.FIELDS)}
                          for a, s_ in enumerate(plan.subs)}
         except Exception as exc:
@@ -599,7 +608,8 @@ def main():
                 roof = valu_bound_roofline(roof, rv, kernels[dom]["mean_ms"])
         out = {
             "metric": METRIC, "value": plan.cells * args.steps / dt, "unit": "cells/s",
-            "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank,
+            **({"rehearsal": "%d ranks share cuda:0, collectives over gloo (OGG_BENCH_ONE_GPU): not a multi-GPU measurement" % world} if rehearsal else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,

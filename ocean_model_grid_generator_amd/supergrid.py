@@ -66,6 +66,20 @@ class SubGridPlan(object):
         self.__dict__.update(scalars)
 
 
+def all_reduce(t, op=None):
+    """torch.distributed.all_reduce of a device tensor: over RCCL where the process group is one (backend "nccl"); through the host
+    where it is gloo -- the CPU tests and the one-GPU rehearsal of bench.py, whose ranks share a card that RCCL will not share."""
+    import torch.distributed as dist
+    kw = {} if op is None else {"op": op}
+    if t.is_cuda and dist.get_backend() == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, **kw)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, **kw)
+    return t
+
+
 class SupergridPlan(object):
     """Host-side size logic of main() (OGG:969-1197, 1268-1313) for its whole flag surface: sub-grid selection (--grids), latitude
     overrides, --enhanced_equatorial (the spliced 1-D axis is built on the host, OGG:349-428, and handed to the lat-lon kernel as an
@@ -737,8 +751,7 @@ class Supergrid(object):
                 if sums is None:
                     t = sum(g.metrics_sums() for g in self.peers if g is not self) + t
             else:
-                import torch.distributed as dist
-                dist.all_reduce(t)
+                all_reduce(t)
         v = t.cpu().numpy()
         out = {}
         for k, s in enumerate(p.subs):

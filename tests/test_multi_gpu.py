@@ -27,10 +27,10 @@ def _port():
         return s.getsockname()[1]
 
 
-def _bench(n, extra):
+def _bench(n, extra, env_extra=None):
     args = ["bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1", "--cpu-sample-div", "0", "--d2h", "0", "--workload", "r2"] + extra
     cmd = [sys.executable] + args   # the plain invocation: for n > 1 bench.py starts its ranks itself (child processes under torch.distributed.run)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -57,6 +57,24 @@ def test_two_ranks_reproduce_one_gpu_bitwise(extra):
     assert two["n_gpus"] == 2 and two["world_size"] == 2 and len(two["per_rank"]) == 2
     assert two["field_checksums"] == one["field_checksums"], (one["field_checksums"], two["field_checksums"])
     assert two["config"]["cells"] == one["config"]["cells"]
+
+
+@pytest.mark.parametrize("n,workload", [(2, "r2"), (4, "r4_om4")])
+def test_n_ranks_rehearsed_on_one_gpu(n, workload):
+    """The whole N-rank run of bench.py on a box with ONE GPU (OGG_BENCH_ONE_GPU=1: every rank on cuda:0, the collectives over gloo
+    because RCCL does not put two ranks on one device): the plain invocation starts its ranks, every rank takes its bands, barriers,
+    the max-over-ranks reduction, the self-check's and the fingerprints' all-reduce, the gathered per-rank lines, ONE JSON line --
+    and the fingerprints of the band-sharded fields equal the single-GPU ones bit for bit."""
+    one = _bench(1, ["--workload", workload, "--power-probe", "0"])
+    many = _bench(n, ["--workload", workload, "--power-probe", "0"], {"OGG_BENCH_ONE_GPU": "1"})
+    assert many["n_gpus"] == n and many["world_size"] == n and "rehearsal" in many
+    assert sorted(r["rank"] for r in many["per_rank"]) == list(range(n)) and all(r["ms_per_step"] > 0 for r in many["per_rank"])
+    assert "error" not in many["field_checksums"] and many["field_checksums"] == one["field_checksums"]
+    assert many["config"]["cells"] == one["config"]["cells"] and many["scaling"] == "strong"
+    assert many["self_check_metrics_error_percent"] and "error" not in many["self_check_metrics_error_percent"]
+    for name, errs in many["self_check_metrics_error_percent"].items():
+        for a, b in zip(errs, one["self_check_metrics_error_percent"][name]):
+            assert (a is None and b is None) or abs(a - b) < 1e-9, (name, errs, one["self_check_metrics_error_percent"][name])
 
 
 def test_checksum_is_independent_of_the_pipeline():
