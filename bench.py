@@ -427,7 +427,9 @@ def main():
     # timed region: exactly K passes.  In pass mode 4-5 of the passes also record HIP events around their three launches
     # (on the launch stream, by the library itself): the per-launch durations of the roofline object come from the timed region.
     sample = sg.launch == "pass" and not use_graph
-    stride = max(1, args.steps // 4)   # 4-5 sampled passes: the four event records cost ~7 us per sampled pass
+    # 4-5 sampled passes on one GPU; 2-3 when the grid is split over ranks: the event records cost ~7 us per sampled pass, which a 40 us
+    # share of the grid notices
+    stride = max(1, args.steps // (4 if world == 1 else 2))
     if sample:
         sg.reserve_pass_events(args.steps // stride + 1)
         events = []
@@ -439,18 +441,22 @@ def main():
             if sample:
                 sg.pass_events = events if k % stride == 0 else None
             sg.run_pass()
-    sync()
-    dt = time.perf_counter() - t0
-    dt_local = dt
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0   # this rank's own K passes (information: per_rank, ms_per_step_slowest_rank) ...
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0         # ... and the contract's number: through the closing barrier + synchronize, MAX over the ranks below
+    dt_slowest = dt_local
     launches = None
     if sample:
         sg.pass_events = events
         launches = sg.pass_launch_times_ms()
         sg.pass_events = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, dt_local], dtype=torch.float64, device=device)
         supergrid.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_slowest = float(t[0].item()), float(t[1].item())
     # self-check, untimed: the reference's CHECK_metrics numbers (OGG:732-770) for the bands now in HBM -- five sums per band on the
     # device and one all-reduce (RCCL) of n_subs x 7 doubles, the only collective of the default pipeline
     self_check = None
@@ -610,6 +616,8 @@ def main():
             "metric": METRIC, "value": plan.cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank,
             **({"rehearsal": "%d ranks share cuda:0, collectives over gloo (OGG_BENCH_ONE_GPU): not a multi-GPU measurement" % world} if rehearsal else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            # information: the slowest rank's own K passes up to ITS synchronize, i.e. without the closing barrier that `value` includes
+            "ms_per_step_slowest_rank": dt_slowest / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
