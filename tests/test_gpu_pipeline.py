@@ -325,6 +325,7 @@ def test_bench_json_contract(tmp_path):
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert 0 < d["ms_per_step_slowest_rank"] <= d["ms_per_step"] * 1.001 and "rehearsal" not in d
     assert d["higher_is_better"] is True and d["unit"] == "cells/s" and "workload" in d["config"]
     assert abs(d["value"] - d["config"]["cells"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
