@@ -421,6 +421,40 @@ def test_main_pass_path_matches_function_level_path(hip, name, tmp_path):
     nc.close()
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_both_orchestrators_agree_on_random_flag_sets(hip, seed):
+    """main() drives the device-resident pass from SupergridPlan's restatement of the reference's size logic (OGG:969-1313);
+    main(path="functions") walks the reference's own sequence and takes every size from the arrays it has just computed, as the
+    reference does.  Two restatements of the same logic: on 40 seeded random flag sets (the generator of tests/test_plan_cpu.py, which
+    holds the plan to the ORACLE on the CPU: poles, doughnut fractions, cuts by row and by angle, match_dy, latitude overrides, --grids
+    subsets, parity) they must produce the same arrays bit for bit -- or raise the same text."""
+    import contextlib
+    import io
+    import ocean_model_grid_generator_amd.ocean_grid_generator as ogg
+    from test_plan_cpu import _flags
+    flags = _flags(seed)
+    out = []
+    for path in ("pass", "functions"):
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                out.append(ogg.main(gridfilename=None, no_changing_meta=True, return_arrays=True, path=path, **flags))
+        except SystemExit as exc:
+            out.append(("exit", str(exc.code)))
+        except Exception as exc:   # noqa: BLE001 -- the text is what is compared
+            out.append(("raise", str(exc)))
+    got, ref = out
+    if isinstance(got, tuple) or isinstance(ref, tuple):
+        if isinstance(got, tuple) and isinstance(ref, tuple) and got[1] != ref[1]:
+            # both refuse, for different reasons: the plan refuses up front what the walk only meets later (a cut that needs a cap
+            # which is not there) -- the kind must still be the same
+            assert got[0] == ref[0], (flags, got, ref)
+        else:
+            assert got == ref, (flags, got if isinstance(got, tuple) else "arrays", ref if isinstance(ref, tuple) else "arrays")
+        return
+    ref = dict(ref, sub={k: dict(zip(FIELDS, v)) for k, v in ref["sub"].items()})
+    _same_as_function_level(got, ref, str(flags))
+
+
 @pytest.mark.parametrize("flags", [
     dict(inverse_resolution=1.0, ensure_nj_even=True, south_cutoff_row=2),      # the reference's own guard rejects the even one of
     dict(inverse_resolution=1.0, ensure_nj_even=True, south_cutoff_row=3),      # these two (OGG:1434): both paths must agree
