@@ -643,6 +643,7 @@ def main():
                                       "(`power`: rocm-smi samples after the timed region; DVFS give-back, DESIGN.md 4)%s"
                                       % (fp["sclk_mhz"], fp["watts"], min(alone),
                                          ("; below that, " + roof["limited_by"]) if roof.get("limited_by") else ""))
+        out["cpu_baseline"] = None   # timed on rank 0 of a one-GPU run only (and not with --cpu-sample-div 0)
         if world == 1 and args.cpu_sample_div > 0:
             cells, cdt = cpu_baseline(flags, args.cpu_sample_div)
             out["cpu_baseline"] = {"value": cells / cdt, "unit": "cells/s", "cores": 1, "kind": "port",
