@@ -433,6 +433,7 @@ def main():
     if sample:
         sg.reserve_pass_events(args.steps // stride + 1)
         events = []
+    carried0 = sg.pass_plan_info()[1]
     t0 = time.perf_counter()
     for k in range(args.steps):
         if use_graph:
@@ -448,6 +449,7 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0         # ... and the contract's number: through the closing barrier + synchronize, MAX over the ranks below
     dt_slowest = dt_local
+    plan_slots, carried1 = sg.pass_plan_info()
     launches = None
     if sample:
         sg.pass_events = events
@@ -618,6 +620,9 @@ def main():
             **({"rehearsal": "%d ranks share cuda:0, collectives over gloo (OGG_BENCH_ONE_GPU): not a multi-GPU measurement" % world} if rehearsal else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             # information: the slowest rank's own K passes up to ITS synchronize, i.e. without the closing barrier that `value` includes
             "ms_per_step_slowest_rank": dt_slowest / args.steps * 1e3,
+            # fused pass: of the K timed passes, how many started with launch B because the previous pass's launch B had built their
+            # tables (every pass builds one set of tables; the passes that record events run launch A themselves) -- DESIGN.md 4.1
+            "pass_plan": {"workspace_slots": plan_slots, "timed_passes_whose_tables_rode_in_the_previous_launch_b": carried1 - carried0},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,

@@ -317,12 +317,30 @@ int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1
 /* The same in two steps, for a caller that runs the pass of one set of bands many times (a rank's step loop): the plan holds the kernel
  * parameters of the launches, their grid sizes and the tiling knobs (the OGG_* environment variables are read when the plan is BUILT), so
  * that a run costs the host its launches and nothing else -- no validation, no planning, no getenv.  The band descriptors are copied:
- * they may be freed after ogg_supergrid_pass_plan_dev returns; the buffers and workspaces they point to must stay.  One pass at a time per
- * plan (its cap workspaces are the plan's).  ogg_supergrid_pass_dev == plan + run + destroy. */
+ * they may be freed after ogg_supergrid_pass_plan_dev returns; the buffers and workspaces they point to must stay.  The runs of a plan
+ * go to ONE stream at a time (switch streams only after synchronising the old one) and come from one host thread.
+ * ogg_supergrid_pass_dev == plan + run + destroy, without what follows.
+ *
+ * The tables of the next pass ride in launch B.  With metrics (or a displaced-pole cap) the first launch of a pass writes only the cap
+ * workspaces -- tables, cleared look-back words and counters -- and what it writes does not depend on the pass before it.  A plan
+ * therefore owns TWO workspaces per cap (slot 0 is the caller's, slot 1 the plan's own device allocation of the same size;
+ * OGG_PASS_SLOTS=1, read when the plan is built, turns this off) and the last workgroups of launch B of one pass do launch A's work for
+ * the next pass in the other slot; that pass then starts with launch B.  One packet less per pass on the stream (3-4.5 us), no second
+ * stream, no flag and no wait: the stream's order is the dependence.  Every pass still builds one set of tables; the first pass of a
+ * plan, and a pass that records events (events5 != NULL, so that they time it), run launch A themselves; the tables the LAST pass of a
+ * plan built for a successor that never came are wasted (a few microseconds).  What the caller sees is unchanged: the outputs of a run
+ * are complete when `stream` has executed it, and nothing of pass k + 1 reaches an output array during pass k (the one output launch
+ * A writes, the j = ny row of the bipolar dx, goes through the workspace and is copied by the tail launch); results are bit-identical
+ * with one slot or two.  ogg_supergrid_pass_plan_destroy waits for the device. */
 int ogg_supergrid_pass_plan_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
                                 const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** plan_out);
-int ogg_supergrid_pass_run_dev(const void* plan, void** events5, double* alg_bytes4, void* stream);
+int ogg_supergrid_pass_run_dev(void* plan, void** events5, double* alg_bytes4, void* stream);
 int ogg_supergrid_pass_plan_destroy(void* plan);
+long ogg_supergrid_pass_plan_slots(const void* plan);          /* workspace slots of the plan: 2, or 1 (every pass runs its own launch A) */
+long ogg_supergrid_pass_plan_carried_runs(const void* plan);   /* runs so far that started with launch B */
+/* Waits for `stream`, then *flags = bit 1 / bit 2: a look-back wait of the displaced-pole mesh / quadrature timed out, in either slot, in
+ * a pass since the slot's words were last cleared.  Results of such a pass are invalid; never observed. */
+int ogg_supergrid_pass_plan_flags_dev(const void* plan, int* flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Device utilities used by the band-sharded pipeline (bench / multi-GPU)

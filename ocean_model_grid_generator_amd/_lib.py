@@ -130,6 +130,7 @@ SIGNATURES = {
                                     ctypes.POINTER(BipolarBand), ctypes.POINTER(DpoleBand), ctypes.POINTER(c_void_p)],
     "ogg_supergrid_pass_run_dev": [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_double), c_void_p],
     "ogg_supergrid_pass_plan_destroy": [c_void_p],
+    "ogg_supergrid_pass_plan_flags_dev": [c_void_p, ctypes.POINTER(c_int), c_void_p],
     "ogg_latlon_supergrid_dev": [c_long, c_long, c_long, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_fill_dev": [c_long, c_double, c_void_p, c_void_p],
@@ -148,7 +149,9 @@ LONG_GETTERS = {"ogg_abi_sizeof": [c_int],
                 "ogg_displaced_pole_quad_workspace_bytes": [c_int, c_long, c_long],
                 "ogg_displaced_pole_grid_workspace_bytes": [c_long, c_long],
                 "ogg_dpole_band_workspace_bytes": [c_int, c_long, c_long],
-                "ogg_latlon_rows_workspace_bytes": [c_int, ctypes.POINTER(LatlonBand), c_long]}
+                "ogg_latlon_rows_workspace_bytes": [c_int, ctypes.POINTER(LatlonBand), c_long],
+                "ogg_supergrid_pass_plan_slots": [c_void_p],
+                "ogg_supergrid_pass_plan_carried_runs": [c_void_p]}
 
 _lib = None
 

@@ -386,6 +386,8 @@ struct QuadParams {
     double* dxq;
     double* dyq;
     double* daq;
+    const double* top_src;   // NULL, or the j = ny row of dxq as the tables kernel left it in the workspace: the tail kernel copies it to
+                             // dxq (a pass whose tables launch runs AHEAD of the stream must not write an output there: ogg_pass.hip)
     QuadNodes q;
     // constants of the algebraic per-point form, filled by plan_quad on the host (IEEE double, the operations a kernel would do) so
     // that they sit in scalar registers: sx = 2 pi / nx, sy = (90 - lat0) PI_180 / ny (OGG:131-132), 1 +- rp^2, 4 rp^2, 2 rp sx,
@@ -686,6 +688,8 @@ __global__ __launch_bounds__(64) void bipolar_quad_tail_kernel(QuadParams p) {
     const unsigned bid = blockIdx.x, nblk = gridDim.x;
     const unsigned count = *p.fix_count;
     const int lane = threadIdx.x, half = lane >> 5, q = lane & 31;
+    if (p.top_src && p.top_out_row >= 0)
+        for (long i = (long)bid * 64 + lane; i < p.nx; i += (long)nblk * 64) p.dxq[p.top_out_row * p.nx + i] = p.top_src[i];
     const int jj = (q < N * N) ? q / N : 0, ii = (q < N * N) ? q % N : 0;
     for (unsigned k0 = bid * 2; k0 < count; k0 += nblk * 2) {  // wave-uniform trip count
         const unsigned k = k0 + half;
@@ -786,7 +790,8 @@ template <int N>
 size_t quad_workspace_bytes(long nx, long ny, long n_cell_rows) {
     constexpr int M = N - 1;
     const size_t tabs = (size_t)(M * ny + 2) * sizeof(BpRow) + (size_t)(M * nx + 1) * sizeof(BpCol);
-    return tabs + 16 + QUAD_LL_CLAIM_WORDS * sizeof(unsigned) + (size_t)(n_cell_rows > 0 ? n_cell_rows : 0) * nx * sizeof(unsigned);
+    const size_t lists = tabs + 16 + QUAD_LL_CLAIM_WORDS * sizeof(unsigned) + (size_t)(n_cell_rows > 0 ? n_cell_rows : 0) * nx * sizeof(unsigned);
+    return (lists + 7) / 8 * 8 + (size_t)nx * sizeof(double);   // + a row of dxq (QuadParams::top_src)
 }
 
 // Launch plan of one quadrature call: which cell rows run the plain algebraic form, which carry the guard, whether the
@@ -796,6 +801,7 @@ struct QuadPlan {
     unsigned gx;                 // strip workgroups along the columns
     bool has_fast, has_guard, has_top;   // has_top: the band owns the j = ny row of dxq (evaluated with the tables)
     QuadRange fast, guard;
+    double* top_buf;             // nx doubles at the end of the workspace (QuadParams::top_src)
 };
 
 template <int N>
@@ -812,6 +818,8 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     p.fix_count = fix_count;
     p.ll_claims = fix_count + 4;
     p.fix_list = fix_count + 4 + QUAD_LL_CLAIM_WORDS;
+    p.top_src = nullptr;
+    out.top_buf = reinterpret_cast<double*>(static_cast<char*>(ws) + need - (size_t)p.nx * sizeof(double));
     p.guard_k = guard_k;
     p.top_out_row = (n_dx_rows > n_cell_rows) ? n_cell_rows : -1;
     const double rp2 = p.rp * p.rp;
@@ -857,7 +865,7 @@ constexpr unsigned FIXUP_BLOCKS = 2048;
 // fix-up of the guarded cells, if this band has rows that carry the guard
 template <int N>
 int launch_quad_tail(const QuadPlan& q, hipStream_t s) {
-    if (!q.has_guard) return OGG_OK;
+    if (!q.has_guard && !(q.p.top_src && q.has_top)) return OGG_OK;
     bipolar_quad_tail_kernel<N><<<FIXUP_BLOCKS, 64, 0, s>>>(q.p);
     OGG_LAUNCH_CHECK();
     return OGG_OK;

@@ -15,6 +15,15 @@
 // (without metrics and without a displaced-pole cap there is no quadrature: launch A then carries the lat-lon strips and the
 // bipolar mesh, and B, C do not exist)
 //
+// The tables of the NEXT pass ride in launch B (PassPipe below).  With metrics, launch A writes nothing but the cap workspaces (tables,
+// cleared look-back words and counters), and what it writes does not depend on the pass before it: a plan handle keeps TWO workspaces
+// per cap and lets the last workgroups of launch B(k) do launch A's work for pass k + 1 in the other one -- they fill the slots the
+// draining strips leave.  Pass k + 1 then starts with launch B: one packet less per pass on the stream (3-4.5 us: whatever follows
+// a kernel on this runtime costs that much, scripts/microbench/stream_overlap.hip), no second stream, no flag, no wait -- the stream's own
+// order is the dependence.  Every pass still builds one set of tables; the first pass of a plan (and a pass that times its launches)
+// runs launch A itself.  The one OUTPUT launch A writes, the j = ny row of the bipolar dx, goes through the workspace and is copied by
+// the tail launch (QuadParams::top_src), so that nothing of pass k + 1 reaches an output array during pass k.
+//
 // The lat-lon workgroups come first in the index space (they are resident from the start and walk their strips grid-stride
 // while the compute workgroups stream through the remaining slots).  Every workgroup runs the same body function as the
 // stand-alone kernels of ogg_latlon_fused.hip / ogg_bipolar.hip, so the results are bit-identical to the function-level
@@ -27,6 +36,10 @@
 #include "ogg_latlon_fused_dev.h"
 
 extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows);
+
+#ifndef OGG_PASS_NEXT_TABLES
+#define OGG_PASS_NEXT_TABLES 1
+#endif
 
 namespace {
 
@@ -64,6 +77,25 @@ struct PassAParams {
     DpMeshParams dm;        // ... and the reset of the look-back words of its mesh
     long n_dm_reset;
 };
+
+// the roles of launch A that write nothing but the cap workspaces (tables, cleared words and counters)
+template <int N>
+OGG_DEV void pass_table_roles(const PassAParams& a, long b) {
+    if (b < a.n_tab) {
+        bipolar_tables_body<N>(a.q, b);
+        return;
+    }
+    b -= a.n_tab;
+    if (b < a.n_dq_tab) {
+        if (a.dq_order == 2)
+            dpole_quad_tables_body<2>(a.dq, b, a.n_dq_tab);
+        else
+            dpole_quad_tables_body<4>(a.dq, b, a.n_dq_tab);
+        return;
+    }
+    b -= a.n_dq_tab;
+    if (b < a.n_dm_reset) dpole_mesh_reset_body(a.dm, b, a.n_dm_reset);
+}
 
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
@@ -112,6 +144,8 @@ struct PassBParams {
     long n_dquad;
     int dq_order;
     int order[5];           // dispatch order of the roles behind the lat-lon strips (ROLE_*)
+    const PassAParams* next;   // NULL, or (device memory) launch A's parameters for the NEXT pass of the plan: its table roles ride at the
+    long n_next;               // end of this launch, n_next workgroups of them (PassPipe)
 };
 
 // roles of launch B's workgroups; PassBParams::order lists them in dispatch order
@@ -145,7 +179,13 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     TlScope tl;
 #endif
     long b = blockIdx.x;
-    const long first_help = (long)gridDim.x - a.share.n_help;
+#if OGG_PASS_NEXT_TABLES
+    if (b >= (long)gridDim.x - a.n_next) {   // (n_next = 0: never)
+        pass_table_roles<N>(*a.next, b - ((long)gridDim.x - a.n_next));
+        return;
+    }
+#endif
+    const long first_help = (long)gridDim.x - a.n_next - a.share.n_help;
     const bool helper = b >= first_help;
     if (b < a.share.n_wg || helper) {
 #ifdef OGG_PASS_TIMELINE
@@ -392,9 +432,11 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
 }
 
 template <int N>
-int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStream_t st) {
+int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStream_t st, bool with_a = true, const PassAParams* next = nullptr,
+                  long n_next = 0) {
     // ev: NULL, or 5 events (entries may be NULL) recorded before launch A and after launches A, B, C and D (bench.py times the
-    // launches with them)
+    // launches with them).  with_a = false: the tables of this pass were built by the previous pass's launch B.  next / n_next: the
+    // table roles launch B carries for the next pass (device copy of that pass's PassAParams, number of workgroups).
     auto mark = [&](int k) -> int {
         if (ev && ev[k]) OGG_HIP_CHECK(hipEventRecord(ev[k], st));
         return OGG_OK;
@@ -402,7 +444,7 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
     if (alg_bytes4)
         for (int k = 0; k < 4; ++k) alg_bytes4[k] = P.alg_bytes[k];
     if (int e = mark(0)) return e;
-    if (P.na > 0) {
+    if (P.na > 0 && with_a) {
         pass_a_kernel<N><<<P.na, PASS_TX, 0, st>>>(P.A);
         OGG_LAUNCH_CHECK();
     }
@@ -416,7 +458,13 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
             OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_max), mx, sizeof(mx)));
         }
 #endif
-        pass_b_kernel<N><<<P.nb, PASS_TX, 0, st>>>(P.B);
+        if (next && n_next > 0) {
+            PassBParams b = P.B;
+            b.next = next, b.n_next = n_next;
+            pass_b_kernel<N><<<P.nb + (unsigned)n_next, PASS_TX, 0, st>>>(b);
+        } else {
+            pass_b_kernel<N><<<P.nb, PASS_TX, 0, st>>>(P.B);
+        }
         OGG_LAUNCH_CHECK();
 #ifdef OGG_PASS_TIMELINE
         if (getenv("OGG_TIMELINE")) {
@@ -519,15 +567,93 @@ int build_pass_plan_any(int n_latlon, const ogg_latlon_band* latlon, long ni1, d
     }
 }
 
-int run_pass_plan_any(const PassPlan& P, void** events5, double* alg_bytes4, void* stream) {
+int run_pass_plan_any(const PassPlan& P, void** events5, double* alg_bytes4, void* stream, bool with_a = true, const PassAParams* next = nullptr,
+                      long n_next = 0) {
     hipStream_t st = ogg::as_stream(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(events5);
     switch (P.order) {
-        case 2: return run_pass_plan<2>(P, ev, alg_bytes4, st);
-        case 3: return run_pass_plan<3>(P, ev, alg_bytes4, st);
-        case 4: return run_pass_plan<4>(P, ev, alg_bytes4, st);
-        default: return run_pass_plan<5>(P, ev, alg_bytes4, st);
+        case 2: return run_pass_plan<2>(P, ev, alg_bytes4, st, with_a, next, n_next);
+        case 3: return run_pass_plan<3>(P, ev, alg_bytes4, st, with_a, next, n_next);
+        case 4: return run_pass_plan<4>(P, ev, alg_bytes4, st, with_a, next, n_next);
+        default: return run_pass_plan<5>(P, ev, alg_bytes4, st, with_a, next, n_next);
     }
+}
+
+// A plan handle: the plan of a pass for each of two workspace slots, launch A's parameters of both in device memory (the table roles
+// that ride in the other slot's launch B read them from there), and which slot's tables the last launch B has built.
+struct PassPipe {
+    int n_slots = 1;                        // 1: every pass runs its own launch A (OGG_PASS_SLOTS=1, or a pass without launch B)
+    PassPlan slot[2];
+    void* own_ws[2] = {nullptr, nullptr};   // slot 1's workspaces (bipolar cap, southern cap): the plan's own allocations
+    PassAParams* dev_a = nullptr;           // [2]
+    unsigned long long runs = 0;            // passes issued
+    int ready_slot = -1;                    // the slot whose tables the previous pass's launch B built
+    unsigned long long carried_runs = 0;    // passes that started with launch B
+    int device = 0;
+
+    ~PassPipe() {
+        if (n_slots > 1) {
+            int current = 0;
+            (void)hipGetDevice(&current);
+            (void)hipSetDevice(device);
+            (void)hipDeviceSynchronize();   // nothing of the plan may still be in flight when its workspaces go
+            for (void* w : own_ws)
+                if (w) (void)hipFree(w);
+            if (dev_a) (void)hipFree(dev_a);
+            (void)hipSetDevice(current);
+        }
+    }
+};
+
+void route_top_row_through_workspace(PassPlan& P) {
+    if (!P.have_quad || !P.qp.has_top) return;
+    P.A.q.dxq = P.qp.top_buf, P.A.q.top_out_row = 0;
+    P.qp.p.top_src = P.qp.top_buf;
+}
+
+int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
+                    const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, PassPipe& H) {
+    if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, south_cap, H.slot[0])) return e;
+    // without launch B, launch A writes the outputs themselves: nothing to carry
+    if (!OGG_PASS_NEXT_TABLES || env_long("OGG_PASS_SLOTS", 2) < 2 || !H.slot[0].launch_b || H.slot[0].na == 0) return OGG_OK;
+    OGG_HIP_CHECK(hipGetDevice(&H.device));
+    const bool have_cap = cap && cap->n_pt_rows > 0 && cap->workspace, have_dp = south_cap && south_cap->n_pt_rows > 0;
+    ogg_bipolar_band c{};
+    ogg_dpole_band d{};
+    if (have_cap) {
+        c = *cap;
+        OGG_HIP_CHECK(hipMalloc(&H.own_ws[0], (size_t)cap->workspace_bytes));
+        OGG_HIP_CHECK(hipMemset(H.own_ws[0], 0, (size_t)cap->workspace_bytes));
+        c.workspace = H.own_ws[0];
+    }
+    if (have_dp) {
+        d = *south_cap;
+        OGG_HIP_CHECK(hipMalloc(&H.own_ws[1], (size_t)south_cap->workspace_bytes));
+        OGG_HIP_CHECK(hipMemset(H.own_ws[1], 0, (size_t)south_cap->workspace_bytes));
+        d.workspace = H.own_ws[1];
+    }
+    H.n_slots = 2;   // from here on ~PassPipe frees what has been allocated
+    if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap ? (have_cap ? &c : cap) : nullptr,
+                                    south_cap ? (have_dp ? &d : south_cap) : nullptr, H.slot[1]))
+        return e;
+    for (PassPlan& P : H.slot) route_top_row_through_workspace(P);
+    OGG_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&H.dev_a), 2 * sizeof(PassAParams)));
+    for (int k = 0; k < 2; ++k) OGG_HIP_CHECK(hipMemcpy(H.dev_a + k, &H.slot[k].A, sizeof(PassAParams), hipMemcpyHostToDevice));
+    OGG_HIP_CHECK(hipDeviceSynchronize());
+    return OGG_OK;
+}
+
+int run_pass_pipe(PassPipe& H, void** events5, double* alg_bytes4, void* stream) {
+    if (H.n_slots == 1) return run_pass_plan_any(H.slot[0], events5, alg_bytes4, stream);
+    const int s = (int)(H.runs & 1ull), o = s ^ 1;
+    // launch A itself on the first pass of the plan, and on a pass that times its launches (the events then time it); otherwise the
+    // previous pass's launch B has built this slot's tables
+    const bool carried = H.ready_slot == s && events5 == nullptr;
+    const int rc = run_pass_plan_any(H.slot[s], events5, alg_bytes4, stream, !carried, H.dev_a + o, (long)H.slot[o].na);
+    H.runs += 1;
+    H.carried_runs += carried ? 1 : 0;
+    H.ready_slot = (rc == OGG_OK) ? o : -1;
+    return rc;
 }
 
 }  // namespace
@@ -550,23 +676,49 @@ extern "C" int ogg_supergrid_pass_plan_dev(int n_latlon, const ogg_latlon_band* 
                                            const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** plan_out) {
     OGG_REQUIRE(plan_out, OGG_EARG, "ogg_supergrid_pass_plan: null plan_out");
     *plan_out = nullptr;
-    PassPlan* P = new (std::nothrow) PassPlan;
-    OGG_REQUIRE(P, OGG_ENOMEM, "ogg_supergrid_pass_plan: out of host memory");
-    if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, south_cap, *P)) {
-        delete P;
+    PassPipe* H = new (std::nothrow) PassPipe;
+    OGG_REQUIRE(H, OGG_ENOMEM, "ogg_supergrid_pass_plan: out of host memory");
+    if (int e = build_pass_pipe(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, south_cap, *H)) {
+        delete H;
         return e;
     }
-    *plan_out = P;
+    *plan_out = H;
     return OGG_OK;
 }
 
-extern "C" int ogg_supergrid_pass_run_dev(const void* plan, void** events5, double* alg_bytes4, void* stream) {
+extern "C" int ogg_supergrid_pass_run_dev(void* plan, void** events5, double* alg_bytes4, void* stream) {
     OGG_REQUIRE(plan, OGG_EARG, "ogg_supergrid_pass_run: null plan");
-    return run_pass_plan_any(*static_cast<const PassPlan*>(plan), events5, alg_bytes4, stream);
+    return run_pass_pipe(*static_cast<PassPipe*>(plan), events5, alg_bytes4, stream);
 }
 
 extern "C" int ogg_supergrid_pass_plan_destroy(void* plan) {
-    delete static_cast<PassPlan*>(plan);
+    delete static_cast<PassPipe*>(plan);
+    return OGG_OK;
+}
+
+extern "C" long ogg_supergrid_pass_plan_slots(const void* plan) { return plan ? static_cast<const PassPipe*>(plan)->n_slots : 0; }
+extern "C" long ogg_supergrid_pass_plan_carried_runs(const void* plan) { return plan ? (long)static_cast<const PassPipe*>(plan)->carried_runs : 0; }
+
+// flags of the plan's passes so far, after waiting for `stream`: bit 1 / bit 2 a look-back wait of the displaced-pole mesh / quadrature
+// timed out, in either workspace slot
+extern "C" int ogg_supergrid_pass_plan_flags_dev(const void* plan, int* flags, void* stream) {
+    OGG_REQUIRE(plan && flags, OGG_EARG, "ogg_supergrid_pass_plan_flags: null pointer");
+    const PassPipe& H = *static_cast<const PassPipe*>(plan);
+    OGG_HIP_CHECK(hipStreamSynchronize(ogg::as_stream(stream)));
+    int f = 0;
+    for (int k = 0; k < H.n_slots; ++k) {
+        const PassPlan& P = H.slot[k];
+        unsigned w = 0u;
+        if (P.B.n_dmesh > 0 && P.B.dm.ticket) {
+            OGG_HIP_CHECK(hipMemcpy(&w, P.B.dm.ticket + 1, sizeof(w), hipMemcpyDeviceToHost));
+            if (w) f |= 2;
+        }
+        if (P.dq_order && P.dq.ticket) {
+            OGG_HIP_CHECK(hipMemcpy(&w, P.dq.ticket + 1, sizeof(w), hipMemcpyDeviceToHost));
+            if (w) f |= 4;
+        }
+    }
+    *flags = f;
     return OGG_OK;
 }
 

@@ -161,7 +161,7 @@ class SupergridPlan(object):
             # Row cost for the band split of the cap, in units of a plain cell row.  The quadrature guards its algebraic per-point form
             # near the two pole points (csrc/ogg_bipolar_dev.h, bp_point_fast): cell rows whose top edge lies above acos(2/sqrt(K))
             # carry the guard (1.3x a plain row).  The band that holds the last row also runs the tail launch (literal fix-up of the
-            # guarded cells), a fixed cost of ~8 us whatever the resolution: that is taken off the last rank's share of EVERY sub-grid
+            # guarded cells), a fixed cost of ~6.5 us whatever the resolution: that is taken off the last rank's share of EVERY sub-grid
             # (rows_of: tail_us / pass_us below), not off its cap rows alone -- a rank's lat-lon strips and cap workgroups end together
             # (timeline of launch B at 1/8 of the 1/8 degree grid: strips 35 us, quadrature 39 us), so a smaller cap share alone left the
             # last rank as slow as before.  (scripts/rank_sweep.py; OGG_BP_ROW_COST="fix,guard,lump" overrides the row weights: rows with
@@ -225,7 +225,7 @@ class SupergridPlan(object):
         if bp is not None and not skip_metrics:
             # the last rank's fix-up launch against a single-GPU pass of this grid (1.08e11 cells/s measured at 1/8 degree): see rows_of
             import os
-            tail_us = float(os.environ.get("OGG_TOP_RANK_TAIL_US", "8"))
+            tail_us = float(os.environ.get("OGG_TOP_RANK_TAIL_US", "6.5"))
             cells = sum(s.nj1 - 1 for s in self.subs) * Ni
             pass_us = cells / 1.08e5
             if sc is not None and sc.kind == "dpole":   # + the displaced-pole quadrature: 0.66 ns per cell literal (launch D), 0.10 ns chord
@@ -477,6 +477,14 @@ class Supergrid(object):
         self.pass_bytes = (ctypes.c_double * 4)()
         L.call("ogg_supergrid_pass_run_dev", handle, evs, self.pass_bytes, st)
         self.pass_events.append(evs)
+
+    def pass_plan_info(self):
+        """(workspace slots of the fused pass's plan, passes so far that started with launch B because the previous pass's launch B had
+        built their tables) -- (0, 0) before the first pass."""
+        if self._pass_args is None:
+            return 0, 0
+        lib = L.load()
+        return int(lib.ogg_supergrid_pass_plan_slots(self._pass_args[4])), int(lib.ogg_supergrid_pass_plan_carried_runs(self._pass_args[4]))
 
     def replan(self):
         """Drop the cached plan of the pass (rebuilt by the next pass: after a change of an OGG_* tiling knob in the environment)."""
@@ -774,6 +782,11 @@ class Supergrid(object):
     def check_lookback_flags(self):
         """Raise if a displaced-pole kernel of the last pass gave up waiting for a strip map (its results would be invalid; the wait
         is bounded so that a launch always drains -- never observed).  Synchronises the stream."""
+        if self._pass_args is not None:   # the plan of the fused pass: the look-back words of BOTH its workspace slots
+            flags = ctypes.c_int(0)
+            L.call("ogg_supergrid_pass_plan_flags_dev", self._pass_args[4], ctypes.byref(flags), self._stream())
+            if flags.value & 6:
+                raise L.OggHipError(L.OGG_EHIP, "displaced-pole %s: a look-back wait timed out" % ("mesh" if flags.value & 2 else "quadrature"))
         for s in self.plan.subs:
             b = self.buf[s.name]
             if s.kind != "dpole" or b["n"] == 0:

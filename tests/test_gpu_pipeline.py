@@ -175,6 +175,48 @@ def test_tripolar_pass_is_bit_identical_to_separate_kernels(sg, name, world):
         assert np.array_equal(kernels[f], fused[f], equal_nan=False), (f, world)
 
 
+@pytest.mark.parametrize("name,world", [("r2", 1), ("r2", 8), ("r0.5_latdp", 1), ("r0.5_dp", 3), ("r1_cut2", 2), ("r2_skip_metrics", 1)])
+def test_tables_of_the_next_pass_ride_in_launch_b(sg, name, world, monkeypatch):
+    """A plan keeps two workspaces per cap; the last workgroups of launch B of pass k build the tables (and clear the look-back words) of
+    pass k + 1 in the other one, and pass k + 1 starts with launch B.  30 passes back to back per rank with EVERY output poisoned on the
+    stream between two passes (nothing of pass k + 1 may reach an output array during pass k: the j = ny row of the bipolar dx goes
+    through the workspace), passes that time their launches (and run launch A themselves) mixed in, against a plan with one slot: all
+    fields bit for bit, no look-back flag, and all but the first pass and the timed ones really started with launch B."""
+    import torch
+    from ocean_model_grid_generator_amd import _lib as L
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    monkeypatch.setenv("OGG_PASS_SLOTS", "1")
+    base = run_pass_mode(sg, plan, world)
+    monkeypatch.delenv("OGG_PASS_SLOTS")
+    out = []
+    for r in range(world):
+        g = sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo="recompute", latlon="fused")
+        g.launch = "pass"
+        g.reserve_pass_events(4)
+        timed = 0
+        for k in range(30):
+            for f in FIELDS:
+                for s in plan.subs:
+                    g.buf[s.name][f].fill_(float("nan"))
+            g.pass_events = [] if k in (7, 8, 20) else None
+            timed += 1 if g.pass_events is not None else 0
+            g.run_pass()
+            if g.pass_events is not None:
+                g.pass_launch_times_ms()
+                g.pass_events = None
+        torch.cuda.synchronize()
+        g.check_lookback_flags()
+        h = g._pass_args[4]
+        lib = L.load()
+        two = not (plan.skip_metrics and not any(s.kind == "dpole" for s in plan.subs))
+        assert lib.ogg_supergrid_pass_plan_slots(h) == (2 if two else 1)
+        assert lib.ogg_supergrid_pass_plan_carried_runs(h) == ((30 - 1 - timed) if two else 0)
+        out.append(g.bands_to_host())
+    got = sg.stitch(plan, out)
+    for f in FIELDS:
+        assert np.array_equal(base[f], got[f], equal_nan=False), f
+
+
 @pytest.mark.parametrize("name,dp_arc", [("r0.5_dp", "literal"), ("r0.5_dp", "chord"), ("r1_cut2", "literal"), ("r0.25_even", "literal")])
 def test_pass_does_not_depend_on_tiling_knobs(sg, name, dp_arc, monkeypatch):
     """Chunk lengths of both quadratures (one row ... the whole cap), rows per workgroup of both meshes, the number of resident lat-lon
