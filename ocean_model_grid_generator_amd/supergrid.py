@@ -225,7 +225,9 @@ class SupergridPlan(object):
         if bp is not None and not skip_metrics:
             # the last rank's fix-up launch against a single-GPU pass of this grid (1.08e11 cells/s measured at 1/8 degree): see rows_of
             import os
-            tail_us = float(os.environ.get("OGG_TOP_RANK_TAIL_US", "6.5"))
+            # measured (events, top rank of 8): 6.5 us at 1/8 degree, 17 us at 1/16 degree -- a launch plus the literal re-evaluation of the
+            # guarded cells, whose number grows with the square of the resolution
+            tail_us = float(os.environ.get("OGG_TOP_RANK_TAIL_US", "%.3f" % (2.9 + 0.0563 * refineR * refineR)))
             cells = sum(s.nj1 - 1 for s in self.subs) * Ni
             pass_us = cells / 1.08e5
             if sc is not None and sc.kind == "dpole":   # + the displaced-pole quadrature: 0.66 ns per cell literal (launch D), 0.10 ns chord
