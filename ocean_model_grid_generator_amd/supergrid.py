@@ -4,7 +4,8 @@ One process per GPU.  Every rank owns a contiguous band of rows of EACH sub-grid
 Mercator, bipolar cap): cost per row differs by ~100x between the lat-lon sub-grids and the caps, so cutting the
 stitched grid into contiguous slabs would not balance.  One pass (default pipeline, ``latlon="fused"``, ``launch="pass"``) is
 
-  ogg_supergrid_pass_dev  three launches on the caller's stream: the quadrature tables; then ONE launch that carries the
+  ogg_supergrid_pass_dev  three launches on the caller's stream (through a plan handle, as Supergrid calls it, the first of them rides
+                          in the previous pass's second): the quadrature tables; then ONE launch that carries the
                           lat-lon row strips (x, y, dx, dy, area, angle_dx from the axis formulas: 48 B written per cell,
                           nothing read), the mesh + angle workgroups of both caps and their quadrature strips side by side; then
                           the literal fix-up of the guarded bipolar cells (a displaced-pole quadrature in the reference's literal
