@@ -1,7 +1,7 @@
 """Time the fused pass of one workload under several settings of ONE environment knob, in one process on one box.
 
 usage: python scripts/env_sweep.py --workload r16 --var OGG_PASS_LL_NT --values 0 1 0 1 [--steps 100] [--set K=V ...]
-(The library reads its tuning knobs from the environment at every call.)
+(The knobs are read when the plan of the pass is built: the plan is rebuilt for every value.)
 """
 import argparse
 import os
@@ -35,6 +35,7 @@ for _ in range(60):
 torch.cuda.synchronize()
 for v in args.values:
     os.environ[args.var] = v
+    sg.replan()   # the knobs are read when the plan of the pass is built
     for _ in range(10):
         sg.run_pass()
     torch.cuda.synchronize()
