@@ -323,8 +323,9 @@ int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1
  *
  * The tables of the next pass ride in launch B.  With metrics (or a displaced-pole cap) the first launch of a pass writes only the cap
  * workspaces -- tables, cleared look-back words and counters -- and what it writes does not depend on the pass before it.  A plan
- * therefore owns TWO workspaces per cap (slot 0 is the caller's, slot 1 the plan's own device allocation of the same size;
- * OGG_PASS_SLOTS=1, read when the plan is built, turns this off) and the last workgroups of launch B of one pass do launch A's work for
+ * therefore owns TWO workspaces per cap (device allocations of its own, of the size of the caller's -- their contents outlive a run,
+ * so the caller's workspace, which other entry points may use between two runs, is left alone; OGG_PASS_SLOTS=1, read when the plan is
+ * built, turns this off: one slot, the caller's) and the last workgroups of launch B of one pass do launch A's work for
  * the next pass in the other slot; that pass then starts with launch B.  One packet less per pass on the stream (3-4.5 us), no second
  * stream, no flag and no wait: the stream's order is the dependence.  Every pass still builds one set of tables; the first pass of a
  * plan, and a pass that records events (events5 != NULL, so that they time it), run launch A themselves; the tables the LAST pass of a

@@ -17,7 +17,7 @@
 //
 // The tables of the NEXT pass ride in launch B (PassPipe below).  With metrics, launch A writes nothing but the cap workspaces (tables,
 // cleared look-back words and counters), and what it writes does not depend on the pass before it: a plan handle keeps TWO workspaces
-// per cap and lets the last workgroups of launch B(k) do launch A's work for pass k + 1 in the other one -- they fill the slots the
+// per cap (its own allocations: their contents outlive a run) and lets the last workgroups of launch B(k) do launch A's work for pass k + 1 in the other one -- they fill the slots the
 // draining strips leave.  Pass k + 1 then starts with launch B: one packet less per pass on the stream (3-4.5 us: whatever follows
 // a kernel on this runtime costs that much, scripts/microbench/stream_overlap.hip), no second stream, no flag, no wait -- the stream's own
 // order is the dependence.  Every pass still builds one set of tables; the first pass of a plan (and a pass that times its launches)
@@ -579,12 +579,14 @@ int run_pass_plan_any(const PassPlan& P, void** events5, double* alg_bytes4, voi
     }
 }
 
-// A plan handle: the plan of a pass for each of two workspace slots, launch A's parameters of both in device memory (the table roles
+// A plan handle: the plan of a pass for each of two workspace slots (both the plan's own), launch A's parameters of both in device memory (the table roles
 // that ride in the other slot's launch B read them from there), and which slot's tables the last launch B has built.
 struct PassPipe {
     int n_slots = 1;                        // 1: every pass runs its own launch A (OGG_PASS_SLOTS=1, or a pass without launch B)
     PassPlan slot[2];
-    void* own_ws[2] = {nullptr, nullptr};   // slot 1's workspaces (bipolar cap, southern cap): the plan's own allocations
+    void* own_ws[2][2] = {};                // [slot][bipolar cap, southern cap]: with two slots BOTH are the plan's own allocations -- what is in
+                                            // them outlives a run (the tables of the next pass), so nobody else may write there; the caller's
+                                            // workspaces are used by a one-slot plan only
     PassAParams* dev_a = nullptr;           // [2]
     unsigned long long runs = 0;            // passes issued
     int ready_slot = -1;                    // the slot whose tables the previous pass's launch B built
@@ -597,8 +599,9 @@ struct PassPipe {
             (void)hipGetDevice(&current);
             (void)hipSetDevice(device);
             (void)hipDeviceSynchronize();   // nothing of the plan may still be in flight when its workspaces go
-            for (void* w : own_ws)
-                if (w) (void)hipFree(w);
+            for (auto& slot_ws : own_ws)
+                for (void* w : slot_ws)
+                    if (w) (void)hipFree(w);
             if (dev_a) (void)hipFree(dev_a);
             (void)hipSetDevice(current);
         }
@@ -618,24 +621,26 @@ int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, doubl
     if (!OGG_PASS_NEXT_TABLES || env_long("OGG_PASS_SLOTS", 2) < 2 || !H.slot[0].launch_b || H.slot[0].na == 0) return OGG_OK;
     OGG_HIP_CHECK(hipGetDevice(&H.device));
     const bool have_cap = cap && cap->n_pt_rows > 0 && cap->workspace, have_dp = south_cap && south_cap->n_pt_rows > 0;
-    ogg_bipolar_band c{};
-    ogg_dpole_band d{};
-    if (have_cap) {
-        c = *cap;
-        OGG_HIP_CHECK(hipMalloc(&H.own_ws[0], (size_t)cap->workspace_bytes));
-        OGG_HIP_CHECK(hipMemset(H.own_ws[0], 0, (size_t)cap->workspace_bytes));
-        c.workspace = H.own_ws[0];
-    }
-    if (have_dp) {
-        d = *south_cap;
-        OGG_HIP_CHECK(hipMalloc(&H.own_ws[1], (size_t)south_cap->workspace_bytes));
-        OGG_HIP_CHECK(hipMemset(H.own_ws[1], 0, (size_t)south_cap->workspace_bytes));
-        d.workspace = H.own_ws[1];
-    }
     H.n_slots = 2;   // from here on ~PassPipe frees what has been allocated
-    if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap ? (have_cap ? &c : cap) : nullptr,
-                                    south_cap ? (have_dp ? &d : south_cap) : nullptr, H.slot[1]))
-        return e;
+    for (int k = 0; k < 2; ++k) {
+        ogg_bipolar_band c{};
+        ogg_dpole_band d{};
+        if (have_cap) {
+            c = *cap;
+            OGG_HIP_CHECK(hipMalloc(&H.own_ws[k][0], (size_t)cap->workspace_bytes));
+            OGG_HIP_CHECK(hipMemset(H.own_ws[k][0], 0, (size_t)cap->workspace_bytes));
+            c.workspace = H.own_ws[k][0];
+        }
+        if (have_dp) {
+            d = *south_cap;
+            OGG_HIP_CHECK(hipMalloc(&H.own_ws[k][1], (size_t)south_cap->workspace_bytes));
+            OGG_HIP_CHECK(hipMemset(H.own_ws[k][1], 0, (size_t)south_cap->workspace_bytes));
+            d.workspace = H.own_ws[k][1];
+        }
+        if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap ? (have_cap ? &c : cap) : nullptr,
+                                        south_cap ? (have_dp ? &d : south_cap) : nullptr, H.slot[k]))
+            return e;
+    }
     for (PassPlan& P : H.slot) route_top_row_through_workspace(P);
     OGG_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&H.dev_a), 2 * sizeof(PassAParams)));
     for (int k = 0; k < 2; ++k) OGG_HIP_CHECK(hipMemcpy(H.dev_a + k, &H.slot[k].A, sizeof(PassAParams), hipMemcpyHostToDevice));

@@ -217,6 +217,32 @@ def test_tables_of_the_next_pass_ride_in_launch_b(sg, name, world, monkeypatch):
         assert np.array_equal(base[f], got[f], equal_nan=False), f
 
 
+@pytest.mark.parametrize("name", ["r0.5_dp", "r0.5_latdp", "r2"])
+def test_function_level_calls_between_two_passes_of_a_plan(sg, name):
+    """What a plan's launch B builds for the next pass lives in workspaces of the plan's own: a caller that runs the stand-alone kernels on
+    ITS workspaces between two passes (Supergrid in "kernels" mode shares them with the pass: tickets taken, look-back words published,
+    counters left non-zero) does not disturb the next pass.  Passes and kernel-mode steps alternate in every phase of the two slots, all
+    outputs poisoned before every pass: the pass's bits every time."""
+    import torch
+    plan = sg.SupergridPlan(**CONFIGS[name])
+    want = run_pass_mode(sg, plan, 1)
+    g = sg.Supergrid(plan, device="cuda:0", halo="recompute", latlon="fused")
+    for k, n_pass in enumerate((1, 2, 1, 3, 2)):
+        g.launch, g.overlap = "kernels", False
+        g.step()
+        g.launch = "pass"
+        for _ in range(n_pass):
+            for f in FIELDS:
+                for s in plan.subs:
+                    g.buf[s.name][f].fill_(float("nan"))
+            g.run_pass()
+        torch.cuda.synchronize()
+        g.check_lookback_flags()
+        got = sg.stitch(plan, [g.bands_to_host()])
+        for f in FIELDS:
+            assert np.array_equal(want[f], got[f], equal_nan=False), (f, k)
+
+
 @pytest.mark.parametrize("name,dp_arc", [("r0.5_dp", "literal"), ("r0.5_dp", "chord"), ("r1_cut2", "literal"), ("r0.25_even", "literal")])
 def test_pass_does_not_depend_on_tiling_knobs(sg, name, dp_arc, monkeypatch):
     """Chunk lengths of both quadratures (one row ... the whole cap), rows per workgroup of both meshes, the number of resident lat-lon
