@@ -424,12 +424,12 @@ def main():
         sg.capture()
         sg.replay()  # one untimed replay
     sync()
-    # timed region: exactly K passes.  In pass mode 4-5 of the passes also record HIP events around their three launches
+    # timed region: exactly K passes.  In pass mode 2-3 of the passes also record HIP events around their three launches
     # (on the launch stream, by the library itself): the per-launch durations of the roofline object come from the timed region.
     sample = sg.launch == "pass" and not use_graph
-    # 4-5 sampled passes on one GPU; 2-3 when the grid is split over ranks: the event records cost ~7 us per sampled pass, which a 40 us
-    # share of the grid notices
-    stride = max(1, args.steps // (4 if world == 1 else 2))
+    # 2-3 sampled passes: the event records cost ~7 us per sampled pass, and a sampled pass runs its table launch itself (~4 us) instead of
+    # finding its tables built by the previous pass's launch B
+    stride = max(1, args.steps // 2)
     if sample:
         sg.reserve_pass_events(args.steps // stride + 1)
         events = []
