@@ -34,6 +34,7 @@ WORKLOADS = {
     "r4_om4": dict(inverse_resolution=4.0, r_dp=0.2, south_cutoff_row=83),           # configs[1]
     "r16": dict(inverse_resolution=16.0),                                            # configs[4]
     "r2": dict(inverse_resolution=2.0),
+    "r32": dict(inverse_resolution=32.0),   # beyond BASELINE.json: 1/32 degree, 405 M cells, 19.4 GB of fields (a size check of the 288 GB part)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 

@@ -618,13 +618,16 @@ def test_reference_own_r8_test_configuration_through_main_vs_oracle(hip):
     _check_supergrid(got, want, "r8_p125")
 
 
-@pytest.mark.parametrize("world,rank", [(1, 0), (8, 7)])
-def test_full_size_properties_r16_on_device(sg, world, rank):
+@pytest.mark.parametrize("r,world,rank", [(16, 1, 0), (16, 8, 7), (32, 1, 0)])
+def test_full_size_properties_r16_on_device(sg, r, world, rank):
     """BASELINE config 5 (1/16 degree, 101 M cells, 4.9 GB of fields) through the fused pass, checked where the fields are:
-    the reference's analytic-sphere self-check from device sums, signs, monotone latitude, the joints."""
+    the reference's analytic-sphere self-check from device sums, signs, monotone latitude, the joints.  And once at 1/32 degree --
+    beyond BASELINE.json: 405 M cells, 19.4 GB of fields in one GPU's HBM -- for the index arithmetic (1464 look-back strips per row, 3.5e8
+    cells in the cap) and the sizing."""
     import torch
-    plan = sg.SupergridPlan(16.0)
-    assert (plan.nyp, plan.Ni + 1) == (8785, 11521) and plan.cells == 8784 * 11520
+    plan = sg.SupergridPlan(float(r))
+    k = r // 16
+    assert (plan.nyp, plan.Ni + 1) == (8784 * k + 1, 11520 * k + 1) and plan.cells == 8784 * k * 11520 * k
     g = sg.Supergrid(plan, rank=rank, world=world, device="cuda:0", halo="recompute")
     assert g.launch == "pass"
     g.step()
