@@ -149,10 +149,20 @@ def _dp_parity(arc):
         rec = json.load(open(os.path.join(ROOT, "profiles", "dp_parity.json")))
     except Exception:
         return None
-    return {"arc_form_timed": arc, "source": "profiles/dp_parity.json (tests/test_gpu_pipeline.py::test_full_size_r8_latdp_pass_vs_oracle on MI355X)",
-            "max_rel_vs_oracle_r8_latdp": {form: {f: v["max_rel"] for f, v in rec["full_size_r8_latdp"][form].items()}
-                                           for form in ("literal", "chord")},
-            "chord_vs_literal_max_rel": rec["full_size_chord_vs_literal_max_rel"]}
+    out = {"arc_form_timed": arc, "source": "profiles/dp_parity.json (tests/test_gpu_pipeline.py::test_full_size_r8_latdp_pass_vs_oracle on MI355X)",
+           "max_rel_vs_oracle_r8_latdp": {form: {f: v["max_rel"] for f, v in rec["full_size_r8_latdp"][form].items()}
+                                          for form in ("literal", "chord")},
+           "chord_vs_literal_max_rel": rec["full_size_chord_vs_literal_max_rel"]}
+    try:   # ... and how far the fp64 reference (oracle) and both forms are from a 50-digit evaluation of the reference's own formula
+        tt = json.load(open(os.path.join(ROOT, "profiles", "r04_truth_table.json")))["dp_quadrature_OGG522_601"]
+        out["max_rel_vs_exact_value_of_the_reference_formula_r8_latdp"] = {
+            who: {f: tt["kept_rows_276_559/" + f][key]["max_rel"] for f in ("dx", "dy", "area")}
+            for who, key in (("fp64_reference_numpy", "oracle_vs_truthA"), ("hip_literal", "hip_literal_vs_truthA"), ("hip_chord", "hip_chord_vs_truthA"))}
+        out["truth_source"] = ("profiles/r04_truth_table.json: tests/test_gpu_truth.py on MI355X against tests/golden/truth_table.npz "
+                               "(scripts/truth_table.py, mpmath 50 digits, 10 500 cells of the kept rows)")
+    except Exception:  # noqa: BLE001 -- the record is optional
+        pass
+    return out
 
 
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4   # wave64 fp64 VALU instructions per ns over the chip: 1024 SIMDs, 2.4 GHz, 4 cycles per instruction
@@ -326,11 +336,12 @@ def main():
     ap.add_argument("--self-check", type=int, default=1, help="after the timed region: % errors of area / arcs per sub-grid (device sums + all-reduce)")
     ap.add_argument("--power-probe", type=float, default=1.5, help="after the timed region (1 GPU): seconds per phase of the rocm-smi power / "
                     "clock probe (fused pass, lat-lon kernel alone, cap kernels alone); 0: skip")
-    ap.add_argument("--dp-arc", default="literal", choices=["chord", "literal"],
+    ap.add_argument("--dp-arc", default="chord", choices=["chord", "literal"],
                     help="arc form of the displaced-pole quadrature that `value` / `ms_per_step` are measured on (workloads with a displaced pole "
-                         "only): literal (default: the reference's haversine arithmetic, what main() and every entry point run unless told "
-                         "otherwise) or chord (opt-in: same finite-difference stencil, distances from the probes' positions on the sphere); "
-                         "both are ~1.3e-9 relative from the CPU oracle at 1/8 degree (`parity`).  The other form is timed after the timed "
+                         "only): chord (default since round 4, what main() and the Python entry points run unless told otherwise: the same "
+                         "finite-difference stencil, distances from the probes' positions on the sphere) or literal (the reference's haversine "
+                         "arithmetic, a fourth launch).  Against a 50-digit evaluation of the reference's own formula the chord form is CLOSER "
+                         "than the fp64 reference itself (profiles/r04_truth_table.json; `parity`).  The other form is timed after the timed "
                          "region and reported as `dp_arc_other` (--dp-arc-other 0: skip)")
     ap.add_argument("--dp-arc-other", type=int, default=1)
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
@@ -369,6 +380,13 @@ def main():
 
     flags = WORKLOADS[args.workload]
     plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **flags)
+    # band split: the last rank's share follows from two timings (the fix-up launch only it runs, a whole pass) that rank 0 takes on
+    # THIS box before any band exists and broadcasts (OGG_SPLIT_CALIBRATE=0: the fitted constants of rounds 2-3)
+    if os.environ.get("OGG_SPLIT_CALIBRATE", "1") != "0":
+        if args.as_rank is not None and args.as_world > 1:
+            plan.calibrate_split(device, rank=0, world=args.as_world, broadcast=False)
+        elif world > 1:
+            plan.calibrate_split(device, rank=rank, world=world)
     if args.as_rank is not None:  # single-GPU rehearsal of one rank's share
         sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device=device, halo="recompute", latlon=args.latlon)
     else:
@@ -429,7 +447,9 @@ def main():
     # (on the launch stream, by the library itself): the per-launch durations of the roofline object come from the timed region.
     sample = sg.launch == "pass" and not use_graph
     # 2-3 sampled passes: the event records cost ~7 us per sampled pass, and a sampled pass runs its table launch itself (~4 us) instead of
-    # finding its tables built by the previous pass's launch B
+    # finding its tables built by the previous pass's launch B.  One rank: they are 2-3 of the K timed passes.  Several ranks (a rank's K
+    # passes are a fraction of a millisecond at 8 ranks): they run right AFTER the timed region, which then holds K plain passes.
+    sample_inside = sample and world == 1
     stride = max(1, args.steps // 2)
     if sample:
         sg.reserve_pass_events(args.steps // stride + 1)
@@ -440,26 +460,35 @@ def main():
         if use_graph:
             sg.replay()
         else:
-            if sample:
+            if sample_inside:
                 sg.pass_events = events if k % stride == 0 else None
             sg.run_pass()
     torch.cuda.synchronize()
-    dt_local = time.perf_counter() - t0   # this rank's own K passes (information: per_rank, ms_per_step_slowest_rank) ...
+    # This rank's own K passes, from the opening barrier + synchronize to ITS synchronize.  A pass has no inter-rank dependency (no
+    # collective, no halo in the default pipeline), so the job's wall time is the MAX of this over the ranks: that is `value`.
+    dt_local = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
-    dt = time.perf_counter() - t0         # ... and the contract's number: through the closing barrier + synchronize, MAX over the ranks below
-    dt_slowest = dt_local
+    # ... and the same through a closing barrier + synchronize (an all-reduce and two host wake-ups: tens of microseconds, which is
+    # noise at one rank's 5 ms and a tenth of the region at eight ranks' 0.7 ms): reported beside it, `ms_per_step_with_closing_barrier`
+    dt_barrier = time.perf_counter() - t0
     plan_slots, carried1 = sg.pass_plan_info()
     launches = None
     if sample:
+        if not sample_inside:
+            for k in range(args.steps // stride + 1):
+                sg.pass_events = events
+                sg.run_pass()
         sg.pass_events = events
         launches = sg.pass_launch_times_ms()
         sg.pass_events = None
+    dt = dt_slowest = dt_local
     if use_dist:
-        t = torch.tensor([dt, dt_local], dtype=torch.float64, device=device)
+        t = torch.tensor([dt_barrier, dt_local], dtype=torch.float64, device=device)
         supergrid.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_slowest = float(t[0].item()), float(t[1].item())
+        dt_barrier, dt_slowest = float(t[0].item()), float(t[1].item())
+        dt = dt_slowest
     # self-check, untimed: the reference's CHECK_metrics numbers (OGG:732-770) for the bands now in HBM -- five sums per band on the
     # device and one all-reduce (RCCL) of n_subs x 7 doubles, the only collective of the default pipeline
     self_check = None
@@ -558,8 +587,8 @@ def main():
             counters_note[fname] = {"key": key, "collected_with_src_hash": h, "quoted": bool(rec) and h == lib_hash}
             return rec if (rec and h == lib_hash) else {}
 
-        pmc = committed("hbm_traffic.json", args.workload + (" --dp-arc chord" if (has_dp and args.dp_arc == "chord") else ""))
-        valu = committed("valu_counters.json", args.workload + (" --dp-arc chord" if (has_dp and args.dp_arc == "chord") else ""))
+        pmc = committed("hbm_traffic.json", args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else ""))
+        valu = committed("valu_counters.json", args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else ""))
         roof_valu = None
         if launches:  # the launches of the fused pass, timed inside the timed region
             n_sampled = launches.pop("sampled_passes")
@@ -619,11 +648,16 @@ def main():
             "metric": METRIC, "value": plan.cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank,
             **({"rehearsal": "%d ranks share cuda:0, collectives over gloo (OGG_BENCH_ONE_GPU): not a multi-GPU measurement" % world} if rehearsal else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            # information: the slowest rank's own K passes up to ITS synchronize, i.e. without the closing barrier that `value` includes
+            # `value` / `ms_per_step`: K passes of the slowest rank, opening barrier + synchronize to its own synchronize (max over ranks)
             "ms_per_step_slowest_rank": dt_slowest / args.steps * 1e3,
+            # the same region through a closing barrier + synchronize (max over ranks): what round 1-3 reported as `ms_per_step`
+            "ms_per_step_with_closing_barrier": dt_barrier / args.steps * 1e3,
+            "timing": "K passes between an opening barrier + synchronize and each rank's own synchronize, max over ranks (a pass holds no "
+                      "inter-rank dependency); launch events %s" % ("of 2-3 of the K passes" if sample_inside else "of extra passes right after the region"),
             # fused pass: of the K timed passes, how many started with launch B because the previous pass's launch B had built their
             # tables (every pass builds one set of tables; the passes that record events run launch A themselves) -- DESIGN.md 4.1
             "pass_plan": {"workspace_slots": plan_slots, "timed_passes_whose_tables_rode_in_the_previous_launch_b": carried1 - carried0},
+            "band_split": plan.split_times,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,

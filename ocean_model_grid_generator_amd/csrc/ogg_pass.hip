@@ -650,6 +650,15 @@ int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, doubl
 
 int run_pass_pipe(PassPipe& H, void** events5, double* alg_bytes4, void* stream) {
     if (H.n_slots == 1) return run_pass_plan_any(H.slot[0], events5, alg_bytes4, stream);
+    // Under stream capture the launches become graph nodes that are REPLAYED: a replay must find nothing that a previous pass left behind, so
+    // the captured pass runs its own launch A (which resets the slot's counters, tickets and look-back words) and builds nobody's next
+    // tables; the host state does not advance (nothing has executed), except that no slot counts as prepared afterwards.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ogg::as_stream(stream), &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone) {
+        const int sc = (int)(H.runs & 1ull);
+        H.ready_slot = -1;
+        return run_pass_plan_any(H.slot[sc], events5, alg_bytes4, stream, true, nullptr, 0);
+    }
     const int s = (int)(H.runs & 1ull), o = s ^ 1;
     // launch A itself on the first pass of the plan, and on a pass that times its launches (the events then time it); otherwise the
     // previous pass's launch B has built this slot's tables

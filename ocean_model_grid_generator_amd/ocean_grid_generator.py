@@ -396,15 +396,27 @@ def numerical_hj(j, i, nx, ny, lon0, lat0, lon_dp, r_dp, eps, order=6):
     return _numerical_h(j, i, nx, ny, lon0, lat0, lon_dp, r_dp, eps, order, "j")
 
 
-def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_default_Re, arc_form="literal"):
+def default_dp_arc():
+    """Arc form of the displaced-pole quadrature where the caller names none: OGG_DP_ARC, else "chord" (closer to the exact value of
+    the reference's formula than the fp64 reference itself; "literal" = the reference's operation sequence)."""
+    arc = os.environ.get("OGG_DP_ARC", "chord")
+    if arc not in ("chord", "literal"):
+        raise ValueError("OGG_DP_ARC must be chord or literal, not %r" % arc)
+    return arc
+
+
+def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_default_Re, arc_form=None):
     """OGG:565-601 (kernels dpole_quad_tables / dpole_quad_kernel: the lattice is evaluated and reduced on chip).
-    ``arc_form`` (not in the reference): "literal" (default) follows the reference's great_arc_distance operation for
-    operation; "chord" takes the same finite-difference stencil's distances from the probes' positions on the sphere --
-    ~7x less arithmetic, not the reference's arithmetic.  Both are ~1.3e-9 relative from a CPU evaluation at 1/8 degree (one ulp of
-    atan2 amplified by the reference's own finite-difference stencil; include/ogg_hip.h, profiles/dp_parity.json)."""
+    ``arc_form`` (not in the reference): how the great-arc distance of two probes of the finite-difference stencil is taken.
+    "chord" (the default, also OGG_DP_ARC): from the probes' positions on the sphere (cross product; no longitude, no unwrap);
+    "literal": the reference's great_arc_distance operation for operation (haversine of projected longitudes and latitudes).
+    Same stencil, same quadrature.  Against the exact value of the reference's own formula (50-digit evaluation,
+    tests/golden/truth_table.npz, 1/8 degree cap of BASELINE config 4) the fp64 reference itself is 1.4e-9 / 9.0e-10 / 1.2e-9
+    (dx / dy / area, max relative) away, the literal form 1.4e-9 / 8.5e-10 / 1.2e-9 and the chord form 7.6e-10 / 2.7e-10 / 8.3e-10
+    (profiles/r04_truth_table.json): the chord form is the more accurate one and ~6x cheaper, hence the default."""
     print("   Calculating displaced pole cap metrics via quadrature ...")
     nx, ny = int(nx), int(ny)
-    form = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[arc_form]
+    form = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[arc_form or default_dp_arc()]
     dxq, dyq, daq = _new(ny + 1, nx), _new(ny, nx + 1), _new(ny, nx)
     L.call("ogg_displaced_pole_metrics_quad_form", form, int(order), nx, ny, float(lon0), float(lat0), float(lon_dp), float(r_dp),
            float(Re), L.ptr(dxq), L.ptr(dyq), L.ptr(daq))
@@ -616,12 +628,13 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
     (nc_stream: byte-swap-on-copy into a pinned ring, pwrite at each variable's offset) -- no per-function staging, no host
     stitching.  ``path="functions"`` (or OGG_MAIN_PATH=functions) runs the reference's own sequence of calls instead, one host-array
     function after the other (main_function_level): the same bits, for checking.  ``dp_arc`` (or OGG_DP_ARC): arc form of the
-    displaced-pole quadrature, "literal" (default) or "chord".  ``return_arrays=True`` additionally returns the six stitched
+    displaced-pole quadrature, "chord" (default; DESIGN.md section 2: closer to the exact value of the reference's formula than the fp64
+    reference is) or "literal" (the reference's operation sequence).  ``return_arrays=True`` additionally returns the six stitched
     fields and the sub-grid pieces (used by tests)."""
     import time
 
     path = path or os.environ.get("OGG_MAIN_PATH", "pass")
-    dp_arc = dp_arc or os.environ.get("OGG_DP_ARC", "literal")
+    dp_arc = dp_arc or default_dp_arc()
     if path == "functions":
         return main_function_level(inverse_resolution, gridfilename, r_dp, lon_dp, lat_dp, exfracdp, south_cutoff_row, south_cutoff_ang,
                                    reproduce_MIDAS_grids, write_subgrid_files, plotem, no_changing_meta, enhanced_equatorial, debug, grids,
@@ -719,7 +732,7 @@ def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=
                         no_changing_meta=False, enhanced_equatorial=0, debug=False, grids="all", match_dy=(), skip_metrics=False,
                         ensure_nj_even=False, shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0,
                         mercator_upper_lat=-99.0, south_ocean_lower_lat=-99.0, south_ocean_upper_lat=-99.0, no_south_cap=False,
-                        return_arrays=False, dp_arc="literal"):
+                        return_arrays=False, dp_arc=None):
     """The reference's own sequence of calls (OGG:855-1449), every callee a host-array function of this module (numpy in, numpy
     out, one staged device call each) and the stitching on the host: what a user gets who swaps the reference's module for this
     one function by function.  main() produces the same bits from one device-resident pass."""

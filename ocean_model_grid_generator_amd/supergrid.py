@@ -92,17 +92,18 @@ class SupergridPlan(object):
     def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0, south_cutoff_ang=-90.0,
                  skip_metrics=False, ensure_nj_even=False, no_south_cap=False, enhanced_equatorial=0, match_dy=(), grids="all",
                  shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0, mercator_upper_lat=-99.0,
-                 south_ocean_lower_lat=-99.0, Re=ogg._default_Re, mercator_axis=None, dp_arc="literal"):
+                 south_ocean_lower_lat=-99.0, Re=ogg._default_Re, mercator_axis=None, dp_arc=None):
         """``mercator_axis`` = (y0, phi_M) lets a caller that already holds the Mercator ordinate range and axis skip the
         two device calls (the CPU tests of the band / halo logic pass values computed elsewhere).  ``dp_arc``: arc form of
-        the displaced-pole quadrature, "literal" (the reference's arithmetic) or "chord" (include/ogg_hip.h).  ``exfracdp=None``:
+        the displaced-pole quadrature, "chord" (default, or OGG_DP_ARC: the form closer to the exact value of the reference's formula,
+        DESIGN.md section 2) or "literal" (the reference's operation sequence; a fourth launch of the pass).  ``exfracdp=None``:
         main()'s own default 0.28*7/4 (OGG:891-892)."""
         import contextlib
         import io
 
         refineS, refineR = 2, inverse_resolution
         self.Re = Re
-        self.dp_arc = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[dp_arc]
+        self.dp_arc = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[dp_arc or ogg.default_dp_arc()]
         self.skip_metrics = skip_metrics
         self.ensure_nj_even = ensure_nj_even
         self.south_cutoff_row, self.south_cutoff_ang = south_cutoff_row, south_cutoff_ang
@@ -233,8 +234,8 @@ class SupergridPlan(object):
             pass_us = cells / 1.08e5
             if sc is not None and sc.kind == "dpole":   # + the displaced-pole quadrature: 0.66 ns per cell literal (launch D), 0.10 ns chord
                 pass_us += (sc.nj1 - 1) * Ni * (6.6e-4 if self.dp_arc == L.DP_ARC_LITERAL else 1.0e-4)
-            for s in self.subs:
-                s.tail_us, s.pass_us = tail_us, pass_us
+            self.set_split_times(tail_us, pass_us, "fitted constants (builder boxes, rounds 2-3): UNVALIDATED on a multi-GPU node; "
+                                 "calibrate_split() replaces them by this box's own timings")
         # Rows that --south_cutoff_row / _ang remove from the stitched grid (OGG:1268-1313) are not generated when the cut is known from the
         # sizes alone -- by row always; by angle on a regular cap, whose latitudes are an axis formula -- just as the doughnut rows are not
         # (OM4: 82 of the displaced-pole cap's 143 kept rows).  The cut of a displaced-pole cap by ANGLE needs the cap's latitudes and is
@@ -251,6 +252,58 @@ class SupergridPlan(object):
             elif c_sc > 0:
                 sc.row0, sc.nj1 = sc.row0 + c_sc, sc.nj1 - c_sc
             self.cut_applied = (c_sc, c_so, gone)
+
+    split_times = None
+
+    def set_split_times(self, tail_us, pass_us, source):
+        """The two numbers the band split takes the last rank's share from (rows_of): `tail_us`, what the bipolar quadrature's fix-up
+        launch -- which only the rank with the top rows runs -- adds to that rank's pass, and `pass_us`, one pass of the whole grid on
+        one GPU.  The same values on every rank give the same edges on every rank."""
+        for s in self.subs:
+            s.tail_us, s.pass_us = float(tail_us), float(pass_us)
+        self.split_times = {"tail_us": float(tail_us), "pass_us": float(pass_us), "source": source}
+
+    def calibrate_split(self, device, rank=0, world=1, passes=40, broadcast=True):
+        """Replace the fitted split constants by a measurement on THIS box, before any band buffer exists: rank 0 runs the whole grid
+        as one rank (`passes` timed passes after 30 warm ones: pass_us; five more with the library's launch events: the fix-up launch,
+        tail_us) and broadcasts the two numbers; every rank then derives the same edges from them.  Needs a GPU on rank 0 and, for
+        world > 1 with ``broadcast``, an initialised process group.  Returns ``split_times`` (None when the split has no such term:
+        one rank, no bipolar cap, --skip_metrics).  OGG_TOP_RANK_TAIL_US in the environment still overrides the tail time."""
+        import os
+        import time
+        if world <= 1 or self.split_times is None:
+            return self.split_times
+        vals = [None]
+        if rank == 0:
+            import torch
+            g = Supergrid(self, rank=0, world=1, device=device, halo="recompute")
+            g.launch, g.overlap = "pass", False
+            for _ in range(30):
+                g.run_pass()
+            torch.cuda.synchronize(g.device)
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                g.run_pass()
+            torch.cuda.synchronize(g.device)
+            pass_us = (time.perf_counter() - t0) / passes * 1e6
+            g.reserve_pass_events(5)
+            g.pass_events = []
+            for _ in range(5):
+                g.run_pass()
+            tail_us = g.pass_launch_times_ms()["pass_tail"]["ms"] * 1e3
+            g.pass_events = None
+            g.close()
+            del g
+            torch.cuda.empty_cache()
+            if os.environ.get("OGG_TOP_RANK_TAIL_US"):
+                tail_us = float(os.environ["OGG_TOP_RANK_TAIL_US"])
+            vals = [(tail_us, pass_us)]
+        if broadcast:
+            import torch.distributed as dist
+            dist.broadcast_object_list(vals, src=0)
+        tail_us, pass_us = vals[0]
+        self.set_split_times(tail_us, pass_us, "measured by rank 0 at plan build (%d passes of the whole grid on one GPU; launch events of 5 more)" % passes)
+        return self.split_times
 
     def south_cut(self, sc_y0=None):
         """(rows cut from the southern cap, rows cut from the Southern Ocean piece, cap removed) by --south_cutoff_row / _ang,
@@ -375,8 +428,10 @@ class Supergrid(object):
         cost = getattr(s, "row_cost", None)
         tail_us, pass_us = getattr(s, "tail_us", 0.0), getattr(s, "pass_us", 0.0)
         cap = 1.0
-        if world > 1 and tail_us > 0.0 and pass_us > 0.0:
-            cap = min(1.0, max(0.3, 1.0 - world * tail_us / pass_us))
+        # (a grid so small, or ranks so many, that the fix-up launch is more than half of a rank's share: the linear correction no longer
+        # describes anything -- equal shares then, rather than a last rank clamped to a sliver or to no rows at all)
+        if world > 1 and tail_us > 0.0 and pass_us > 0.0 and world * tail_us / pass_us <= 0.5:
+            cap = min(1.0, 1.0 - world * tail_us / pass_us)
         if cost is None and cap == 1.0:
             return band(s.nj1, rank, world)
         return band_weighted(np.ones(s.nj1) if cost is None else cost, rank, world, cap)
@@ -494,6 +549,11 @@ class Supergrid(object):
         if self._pass_args is not None:
             L.call("ogg_supergrid_pass_plan_destroy", self._pass_args[4])
             self._pass_args = None
+
+    def close(self):
+        """Release the plan of the pass (its workspace slots are device allocations of the library) at a point of the caller's choosing
+        rather than at garbage-collection time."""
+        self.replan()
 
     def __del__(self):
         try:

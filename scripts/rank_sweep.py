@@ -18,7 +18,7 @@ ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--workload", default="r8")
 ap.add_argument("--cost", nargs="*", default=["1.3,1.3,0"])
 ap.add_argument("--rounds", type=int, default=2, help="every rank is timed this many times (forwards, then backwards, ...); the best time counts")
-ap.add_argument("--dp-arc", default="literal")
+ap.add_argument("--dp-arc", default="chord")
 ap.add_argument("--json", default=None, help="append one JSON line per (world, cost) to this file")
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--launch", default="pass")
@@ -27,6 +27,8 @@ args = ap.parse_args()
 for cost in args.cost:
     os.environ["OGG_BP_ROW_COST"] = cost
     plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **bench.WORKLOADS[args.workload])
+    if os.environ.get("OGG_SPLIT_CALIBRATE", "1") != "0":   # the split bench.py uses: tail / pass timed on this box (one process: no broadcast)
+        plan.calibrate_split("cuda:0", rank=0, world=args.world, broadcast=False)
     ts = []
     order = [args.world - 1]   # the first entry is a throw-away (clock ramp, allocator warm-up)
     for k in range(args.rounds):
@@ -60,7 +62,7 @@ for cost in args.cost:
         import json
         with open(args.json, "a") as f:
             f.write(json.dumps({"workload": args.workload, "dp_arc": args.dp_arc, "world": args.world, "row_cost": cost, "launch": args.launch,
-                                "steps": args.steps, "ms_per_rank": ts, "ms_slowest_rank": max(ts),
+                                "steps": args.steps, "band_split": plan.split_times, "ms_per_rank": ts, "ms_slowest_rank": max(ts),
                                 "note": "each rank's share of the band split timed on ONE GPU, one after the other (rehearsal; no "
                                         "multi-GPU hardware curve exists yet)"}) + "\n")
     print("world %d cost %s: max %.4f ms  [%s]" % (args.world, cost, max(ts), " ".join("%.4f" % t for t in ts)), flush=True)

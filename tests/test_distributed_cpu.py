@@ -129,3 +129,71 @@ def test_plan_shapes_match_reference_runs():
         plan = _plan(sg_mod, flags.pop("inverse_resolution"), **flags)
         assert [plan.nyp, plan.Ni + 1] == cfgs[name]["shapes"]["x"], name
         assert plan.cells == cfgs[name]["shapes"]["area"][0] * cfgs[name]["shapes"]["area"][1]
+
+
+def test_split_times_give_every_rank_the_same_edges_and_cover_every_row():
+    """The band split with a MEASURED pair (tail_us, pass_us) (SupergridPlan.calibrate_split -> set_split_times): whatever the two
+    numbers, every sub-grid's rows are covered exactly once, the last rank's share shrinks as the fix-up launch grows, and a tail
+    that is more than half of a rank's share switches the correction off (equal shares) instead of starving the last rank."""
+    import ocean_model_grid_generator_amd.supergrid as sg_mod
+    rng = np.random.default_rng(4)
+    for r in (0.5, 2, 8):
+        plan = _plan(sg_mod, r)
+        assert plan.split_times and "UNVALIDATED" in plan.split_times["source"]
+        for world in (2, 4, 8):
+            for _ in range(6):
+                tail, whole = float(rng.uniform(1, 40)), float(rng.uniform(20, 5000))
+                plan.set_split_times(tail, whole, "test")
+                for s in plan.subs:
+                    rows = []
+                    for k in range(world):
+                        lo, hi = sg_mod.Supergrid.rows_of(s, k, world)
+                        assert 0 <= lo <= hi <= s.nj1
+                        rows += list(range(lo, hi))
+                    assert rows == list(range(s.nj1)), (r, world, s.name)
+                    last = sg_mod.Supergrid.rows_of(s, world - 1, world)
+                    if world * tail / whole > 0.5 and getattr(s, "row_cost", None) is None:
+                        assert last == sg_mod.band(s.nj1, world - 1, world)
+    plan = _plan(sg_mod, 8)
+    merc = next(s for s in plan.subs if s.name == "Merc")
+    shares = []
+    for tail in (0.0001, 5.0, 10.0, 15.0):
+        plan.set_split_times(tail, 250.0, "test")
+        lo, hi = sg_mod.Supergrid.rows_of(merc, 7, 8)
+        shares.append(hi - lo)
+    assert shares == sorted(shares, reverse=True) and shares[0] > shares[-1]
+
+
+def _calib_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ocean_model_grid_generator_amd.supergrid as sg_mod
+        plan = _plan(sg_mod, 2)
+        if rank == 0:
+            # no GPU here: rank 0's measurement is replaced by fixed numbers; the broadcast and what follows are the real code
+            vals = [(7.25, 123.5)]
+            dist.broadcast_object_list(vals, src=0)
+            plan.set_split_times(vals[0][0], vals[0][1], "test")
+        else:
+            plan.calibrate_split("cpu", rank=rank, world=world)
+        q.put((rank, plan.split_times["tail_us"], plan.split_times["pass_us"],
+               [sg_mod.Supergrid.rows_of(s, k, world) for s in plan.subs for k in range(world)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calibrated_split_is_broadcast_from_rank_0():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_calib_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res[0][1:] == res[1][1:] and res[0][1] == 7.25 and res[0][2] == 123.5

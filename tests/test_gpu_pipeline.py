@@ -43,6 +43,14 @@ CONFIGS = {
 }
 
 
+def plan_for(sg, name, **kw):
+    """SupergridPlan of CONFIGS[name]; "name+literal" / "name+chord" name the arc form of the displaced-pole quadrature explicitly (the
+    default is the chord form since round 4; the literal form -- the reference's operation sequence, a fourth launch with its own
+    look-back words -- keeps every pipeline test it had while it was the default)."""
+    base, _, arc = name.partition("+")
+    return sg.SupergridPlan(**CONFIGS[base], **({"dp_arc": arc} if arc else {}), **kw)
+
+
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_pipeline_vs_oracle(sg, name):
     flags = dict(CONFIGS[name])
@@ -57,10 +65,10 @@ def test_pipeline_vs_oracle(sg, name):
     _check_supergrid(got, want, "pipe_" + name)
 
 
-@pytest.mark.parametrize("name", ["r1_cut2", "r0.5_dp"])
+@pytest.mark.parametrize("name", ["r1_cut2", "r0.5_dp", "r0.5_dp+literal"])
 @pytest.mark.parametrize("world,halo", [(2, "local"), (3, "local"), (8, "local"), (5, "recompute")])
 def test_band_decomposition_is_bit_invariant(sg, name, world, halo):
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     one = run(sg, plan, 1)
     many = run(sg, plan, world, halo)
     for f in FIELDS:
@@ -71,7 +79,7 @@ def test_band_decomposition_is_bit_invariant(sg, name, world, halo):
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_fused_latlon_kernel_is_bit_identical_to_stencil(sg, name, world):
     """The fused lat-lon kernel (no HBM reads, no halo) against tile + generic stencil kernel, sharded or not."""
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     stencil = run(sg, plan, 1, latlon="stencil")
     fused = run(sg, plan, world, latlon="fused")
     for f in FIELDS:
@@ -81,7 +89,7 @@ def test_fused_latlon_kernel_is_bit_identical_to_stencil(sg, name, world):
 @pytest.mark.parametrize("name", ["r1_cut2", "r2_skip_metrics", "r0.25_even"])
 def test_row_ordered_latlon_kernel_is_bit_identical(sg, name, monkeypatch):
     """ogg_latlon_supergrid_rows_ws_dev ((field, row)-ordered workgroups fed from tables) against the column-tile kernel."""
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     monkeypatch.setenv("OGG_LATLON_ROWS", "0")
     tiles = run(sg, plan, 1, latlon="fused")
     monkeypatch.setenv("OGG_LATLON_ROWS", "1")
@@ -90,13 +98,13 @@ def test_row_ordered_latlon_kernel_is_bit_identical(sg, name, monkeypatch):
         assert np.array_equal(tiles[f], rows[f]), f
 
 
-@pytest.mark.parametrize("name", ["r1_cut2", "r0.5_dp", "r2_skip_metrics"])
+@pytest.mark.parametrize("name", ["r1_cut2", "r0.5_dp", "r0.5_dp+literal", "r2_skip_metrics"])
 @pytest.mark.parametrize("world", [2, 5])
 def test_band_sharded_ranks_write_one_netcdf_file(sg, name, world, tmp_path):
     """Every rank of a band-sharded run streams its own bands into ONE NetCDF file at their byte offsets (rank 0 writes the header;
     no gather): the file is byte-identical to the one a single rank writes."""
     import torch
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     one = sg.Supergrid(plan, device="cuda:0")
     one.step()
     cut = one.south_cut()
@@ -164,18 +172,19 @@ def run_pass_mode(sg, plan, world=1):
     return sg.stitch(plan, out)
 
 
-@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r2_skip_metrics", "r0.5_dp", "r0.5_latdp", "r0.25_even"])
+@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r2_skip_metrics", "r0.5_dp", "r0.5_latdp", "r0.5_dp+literal", "r0.5_latdp+literal", "r0.25_even"])
 @pytest.mark.parametrize("world", [1, 2, 8])
 def test_tripolar_pass_is_bit_identical_to_separate_kernels(sg, name, world):
     """ogg_tripolar_pass_dev (lat-lon strips and cap workgroups sharing three launches) against one launch per sub-grid and phase."""
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     kernels = run(sg, plan, 1, latlon="fused")
     fused = run_pass_mode(sg, plan, world)
     for f in FIELDS:
         assert np.array_equal(kernels[f], fused[f], equal_nan=False), (f, world)
 
 
-@pytest.mark.parametrize("name,world", [("r2", 1), ("r2", 8), ("r0.5_latdp", 1), ("r0.5_dp", 3), ("r1_cut2", 2), ("r2_skip_metrics", 1)])
+@pytest.mark.parametrize("name,world", [("r2", 1), ("r2", 8), ("r0.5_latdp", 1), ("r0.5_dp", 3), ("r0.5_latdp+literal", 1), ("r0.5_dp+literal", 3),
+                                        ("r1_cut2", 2), ("r2_skip_metrics", 1)])
 def test_tables_of_the_next_pass_ride_in_launch_b(sg, name, world, monkeypatch):
     """A plan keeps two workspaces per cap; the last workgroups of launch B of pass k build the tables (and clear the look-back words) of
     pass k + 1 in the other one, and pass k + 1 starts with launch B.  30 passes back to back per rank with EVERY output poisoned on the
@@ -184,7 +193,7 @@ def test_tables_of_the_next_pass_ride_in_launch_b(sg, name, world, monkeypatch):
     fields bit for bit, no look-back flag, and all but the first pass and the timed ones really started with launch B."""
     import torch
     from ocean_model_grid_generator_amd import _lib as L
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     monkeypatch.setenv("OGG_PASS_SLOTS", "1")
     base = run_pass_mode(sg, plan, world)
     monkeypatch.delenv("OGG_PASS_SLOTS")
@@ -217,14 +226,62 @@ def test_tables_of_the_next_pass_ride_in_launch_b(sg, name, world, monkeypatch):
         assert np.array_equal(base[f], got[f], equal_nan=False), f
 
 
-@pytest.mark.parametrize("name", ["r0.5_dp", "r0.5_latdp", "r2"])
+@pytest.mark.parametrize("name", ["r0.5_dp", "r0.5_latdp+literal", "r0.5_dp+literal", "r2"])
+def test_captured_pass_replays_from_a_clean_slot(sg, name):
+    """A pass captured into a HIP graph (Supergrid.capture: one eager pass, then the capture) is REPLAYED many times: the captured pass
+    must run its own launch A -- counters, tickets and look-back words reset on every replay -- and carry nobody's next tables
+    (ogg_pass.hip run_pass_pipe: hipStreamIsCapturing).  Five replays with every output poisoned in between, then eager passes again
+    (the plan must not believe that the captured pass prepared a slot): the eager bits every time, no look-back flag, and the plan's
+    run counter unchanged by the capture."""
+    import torch
+    from ocean_model_grid_generator_amd import _lib as L
+    plan = plan_for(sg, name)
+    want = run_pass_mode(sg, plan, 1)
+    g = sg.Supergrid(plan, device="cuda:0", halo="recompute", latlon="fused")
+    g.launch = "pass"
+    for _ in range(3):
+        g.run_pass()
+    torch.cuda.synchronize()
+    lib = L.load()
+    carried0 = lib.ogg_supergrid_pass_plan_carried_runs(g._pass_args[4])
+    g.capture()                         # one more eager pass + the capture
+    carried1 = lib.ogg_supergrid_pass_plan_carried_runs(g._pass_args[4])
+    assert carried1 - carried0 <= 1     # the eager pass of capture() may have been carried; the captured one is not counted
+
+    def poison():
+        for f in FIELDS:
+            for s_ in plan.subs:
+                g.buf[s_.name][f].fill_(float("nan"))
+
+    def check(tag):
+        torch.cuda.synchronize()
+        g.check_lookback_flags()
+        got = sg.stitch(plan, [g.bands_to_host()])
+        for f in FIELDS:
+            assert np.array_equal(want[f], got[f]), (tag, f)
+
+    for k in range(5):
+        poison()
+        g.replay()
+        check("replay %d" % k)
+    for k in range(3):                   # eager again, straight after replays: launch A must run (no slot is 'ready')
+        poison()
+        g.run_pass()
+        check("eager %d after replays" % k)
+    poison()
+    g.replay()
+    check("replay after eager passes")
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["r0.5_dp", "r0.5_latdp", "r0.5_dp+literal", "r0.5_latdp+literal", "r2"])
 def test_function_level_calls_between_two_passes_of_a_plan(sg, name):
     """What a plan's launch B builds for the next pass lives in workspaces of the plan's own: a caller that runs the stand-alone kernels on
     ITS workspaces between two passes (Supergrid in "kernels" mode shares them with the pass: tickets taken, look-back words published,
     counters left non-zero) does not disturb the next pass.  Passes and kernel-mode steps alternate in every phase of the two slots, all
     outputs poisoned before every pass: the pass's bits every time."""
     import torch
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     want = run_pass_mode(sg, plan, 1)
     g = sg.Supergrid(plan, device="cuda:0", halo="recompute", latlon="fused")
     for k, n_pass in enumerate((1, 2, 1, 3, 2)):
@@ -402,13 +459,13 @@ def test_bench_json_contract(tmp_path):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "cells/s" and c["sample"]
 
 
-@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r0.5_dp", "r0.5_latdp"])
+@pytest.mark.parametrize("name", ["r1_cut2", "r2", "r0.5_dp", "r0.5_latdp", "r0.5_dp+literal"])
 @pytest.mark.parametrize("world", [1, 3])
 def test_metrics_error_on_device(sg, name, world):
     """Supergrid.metrics_error (five device sums per band + one sum over the ranks) against the reference's function
     (oracle restatement) applied to the whole sub-grid arrays."""
     import torch
-    plan = sg.SupergridPlan(**CONFIGS[name])
+    plan = plan_for(sg, name)
     ranks = []
     for r in range(world):
         ranks.append(sg.Supergrid(plan, rank=r, world=world, device="cuda:0", halo="local", peers=ranks, latlon="fused"))

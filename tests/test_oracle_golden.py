@@ -140,3 +140,58 @@ def test_chksum_known_answer(capsys):
     out, _ = capsys.readouterr()
     assert out == ("fc62429c3e69001d65972cdeb94fb9aa18a7d9c16bc449e1e474e7e41bb95a7d          a min = 0.000000000000000 "
                    "max = 1.000000000000000 mean = 0.500000000000000 sd = 0.500000000000000\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the extended-precision truth table (scripts/truth_table.py -> golden/truth_table.npz): the oracle's distance from the
+# exact value of the reference's own formulas is the unit of the GPU tolerances in tests/test_gpu_truth.py
+# ---------------------------------------------------------------------------------------------------------------
+def _err(v, t):
+    return np.abs((v - t[..., 0]) - t[..., 1])
+
+
+def test_truth_table_midas_and_bipolar():
+    T = np.load(os.path.join(GOLD, "truth_table.npz"))
+    for Ni in (5760, 11520):
+        tag = "md%d_" % Ni
+        xa, ya, cols, rows = T[tag + "xaxis"], T[tag + "yaxis"], T[tag + "cols"], T[tag + "rows"]
+        pair = np.stack([cols, cols + 1], 1).reshape(-1)
+        o = orc.generate_grid_metrics_MIDAS(np.tile(xa[pair], (ya.size, 1)), np.tile(ya[:, None], (1, pair.size)))
+        for k, f in enumerate(("dx", "dy", "area")):
+            t = T[tag + f]
+            rel = (_err(o[k][:, ::2][rows], t) / np.abs(t[..., 0])).max()
+            assert rel <= 2.0 * float(T[tag + f + "_eref_rel"]), (Ni, f, rel)
+        # the reference's own fp64 area is several 1e-6 m^2 away from the exact value of its own formula (north_star asks 1e-6)
+        assert 2e-6 < float(T[tag + "area_eref_abs"]) < 5e-5
+        assert float(T[tag + "dx_eref_rel"]) < 1e-15 and float(T[tag + "dy_eref_rel"]) < 1e-15
+    for Ni in (5760, 11520):
+        tag = "bp%d_" % Ni
+        _, Nj, lat0, lon_bp, rp = T[tag + "params"]
+        jj, ii = T[tag + "j"], T[tag + "i"]
+        assert T[tag + "same_branch"].all()
+        lon_g = lon_bp + np.arange(Ni + 1) * 360.0 / float(Ni)
+        latg0 = lat0 + np.arange(int(Nj) + 1) * (90 - lat0) / float(Nj)
+        ol, op, _, _ = orc.bipolar_projection(lon_g[ii][None, :], latg0[jj][None, :], float(lon_bp), float(rp))
+        pole = jj == int(Nj)
+        assert _err(ol[0], T[tag + "lams"])[~pole].max() <= 2.0 * float(T[tag + "lams_eref_meridian"])
+        assert _err(op[0], T[tag + "phis"]).max() <= 2.0 * max(float(T[tag + "phis_eref_meridian"]), float(T[tag + "phis_eref_polerow"]))
+        # the reference itself is 8e-12 (1/8 degree) / 1.7e-11 (1/16 degree) away from the exact longitude next to the symmetry meridians
+        assert 5e-12 < float(T[tag + "lams_eref_meridian"]) < 5e-11
+
+
+def test_truth_table_displaced_pole_rows():
+    T = np.load(os.path.join(GOLD, "truth_table.npz"))
+    nx, ny, lon0, lat0, lon_dp, r_dp, order = T["dp_params"]
+    jj, ii, kept = T["dp_j"], T["dp_i"], T["dp_kept"]
+    assert kept.sum() >= 10000
+    for j in (276, 410, 559):
+        o = orc.displacedPoleCap_metrics_quad(int(order), int(nx), int(ny), lon0, lat0, lon_dp, r_dp, j_first=j, j_last=j + 1)
+        m = jj == j
+        for k, f in enumerate(("dx", "dy", "area")):
+            for A in "AB":
+                t = T["dp_%s_%s" % (A, f)][m]
+                rel = (_err(o[k][j, ii[m]], t) / np.abs(t[:, 0])).max()
+                assert rel <= 2.0 * float(T["dp_%s_%s_eref" % (A, f)]), (j, f, A, rel)
+    # the fp64 reference is ~1e-9 (relative) away from the exact value of its own finite-difference quadrature at 1/8 degree
+    for f in ("dx", "dy", "area"):
+        assert 5e-10 < float(T["dp_A_%s_eref" % f]) < 3e-9
