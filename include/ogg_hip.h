@@ -356,7 +356,8 @@ int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream);
  * 7: atan2(y, x) with their coefficients in vector registers (the literal displaced-pole quadrature's forms); 8: atan2(y, x) with its
  * quotient taken without scaling (finite arguments, the larger one within 2^-300 .. 2^300); 9: atan2(y, x) for ANY arguments, infinities
  * and NaNs included (the generic stencil kernel's form; two NaNs count as equal); 10: cos (x), 11 / 12: the sine / cosine of sincos (x)
- * with their constants as scalar operands (any x; 2^30 and above, infinities and NaNs go to the library).  The number of k < n for which the
+ * with their constants as scalar operands (any x; 2^30 and above, infinities and NaNs go to the library); 13 / 14: mdist(x, y) (OGG:682-684) from
+ * one reduction (the generic stencil kernel's form) / from two, against numpy.mod's own fmod form.  The number of k < n for which the
  * restatement differs IN ANY BIT from the library's own function is ADDED to *n_diff (device memory, 8 bytes, zeroed by the caller). */
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream);
 /* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:

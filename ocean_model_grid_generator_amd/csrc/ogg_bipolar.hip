@@ -37,6 +37,13 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
         } else if (which == 9) {              // atan2 for any arguments (infinities, NaNs)
             a = atan2_lib_any(y[k], x[k]), b = atan2(y[k], x[k]);
             if (a != a && b != b) b = a;      // any NaN is the same answer
+        } else if (which == 13 || which == 14) {   // mdist from one reduction / from two fma reductions, against numpy.mod's own fmod form
+            a = (which == 13) ? mdist_one(x[k], y[k]) : mdist(x[k], y[k]);
+            double m1 = fmod(x[k] - y[k], 360.0), m2 = fmod(y[k] - x[k], 360.0);
+            m1 = (m1 < 0.0) ? m1 + 360.0 : m1, m2 = (m2 < 0.0) ? m2 + 360.0 : m2;
+            m1 = (m1 == 0.0) ? 0.0 : m1, m2 = (m2 == 0.0) ? 0.0 : m2;
+            b = fmin(m1, m2);
+            if (a != a && b != b) b = a;
         } else {                              // which == 10: cos; 11 / 12: the sine / cosine of sincos -- restated with scalar constants
             TrigCoefs t;
             t.load(kTrigRed);
@@ -62,7 +69,8 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
 extern "C" {
 
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream) {
-    OGG_REQUIRE(which >= 0 && which <= 12 && n >= 0 && x && n_diff && ((which != 2 && which != 5 && which != 7 && which != 8 && which != 9) || y), OGG_EARG,
+    OGG_REQUIRE(which >= 0 && which <= 14 && n >= 0 && x && n_diff &&
+                    ((which != 2 && which != 5 && which != 7 && which != 8 && which != 9 && which != 13 && which != 14) || y), OGG_EARG,
                 "ogg_libm_check: bad argument");
     if (n == 0) return OGG_OK;
     libm_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(which, n, x, y, n_diff);

@@ -32,8 +32,10 @@ OGG_DEV double pymod360(double a) {
             q -= 1.0;
             r = fma(-q, 360.0, a);
         } else if (r >= 360.0) {
-            q += 1.0;
-            r = fma(-q, 360.0, a);
+            // q one too small -- or not: for -2.8e-14 < a < 0 the exact a + 360 ROUNDS to 360.0, which is numpy's answer too
+            // (fmod(a) + 360, rounded); the quotient was right then and the retry would come out negative
+            const double r2 = fma(-(q + 1.0), 360.0, a);
+            r = (r2 >= 0.0) ? r2 : r;
         }
     } else {
         r = fmod(a, 360.0);
@@ -50,7 +52,7 @@ OGG_DEV double pymod360_sel(double a) {
     const double r = fma(-q, 360.0, a);
     const double qc = (r < 0.0) ? q - 1.0 : q + 1.0;
     const double rc = fma(-qc, 360.0, a);
-    const double v = (r < 0.0 || r >= 360.0) ? rc : r;
+    const double v = (r < 0.0 || (r >= 360.0 && rc >= 0.0)) ? rc : r;    // (r = 360.0 by rounding, rc < 0: see pymod360)
     return (v == 0.0) ? 0.0 : v;
 }
 OGG_DEV double mdist_sel(double x1, double x2) {
@@ -69,6 +71,21 @@ OGG_DEV double div_pi180(double a) {
 // OGG:682-684 mdist: positive distance modulo 360.
 OGG_DEV double mdist(double x1, double x2) {
     return fmin(pymod360(x1 - x2), pymod360(x2 - x1));
+}
+
+// mdist from ONE reduction.  x2 - x1 = -(x1 - x2) exactly, fmod is exact and odd, so with f = fmod(|d|, 360) in [0, 360) the two
+// numpy.mod of OGG:684 are f and fl(360 - f) (in the order of the sign of d; both 0 when f = 0), and their minimum is
+// fmin(f, 360 - f): half the instructions of two reductions, the same bits (ogg_libm_check_dev, which = 13, against the fmod form).
+// A wave with |d| >= 1e12, an infinity or a NaN takes mdist, behind one ballot.
+OGG_DEV double mdist_one(double x1, double x2) {
+    const double a = fabs(x1 - x2);
+    if (__builtin_expect(__ballot(!(a < 1.0e12)) != 0ull, 0)) return mdist(x1, x2);
+    const double q = floor(a * (1.0 / 360.0));
+    const double r = fma(-q, 360.0, a);                      // exact: a - 360 q is representable
+    const double qc = (r < 0.0) ? q - 1.0 : q + 1.0;         // the quotient from a * (1/360) can be off by one next to a multiple of 360
+    const double rc = fma(-qc, 360.0, a);
+    const double f = (r < 0.0 || r >= 360.0) ? rc : r;       // (exact values: r >= 360 means q was one too small)
+    return fmin(f, 360.0 - f);
 }
 
 // IEEE 1/x and sqrt(x) -- correctly rounded, the SAME bits as the compiler's expansions of `1.0 / x` and `sqrt(x)` -- for operands

@@ -135,6 +135,30 @@ def test_midas_ragged_shapes(ogg, shape):
     assert maxabs(ogg.angle_x(x, y), orc.angle_x(x, y)) < 1e-11
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (5, 63), (7, 258), (31, 513), (200, 1000), (64, 5761)])
+def test_midas_tile_heights_and_streaming_kernel_agree_bitwise(ogg, shape, monkeypatch):
+    """Two implementations of the generic stencil kernel -- the LDS-staged tile walk (mdist from one reduction, non-temporal stores)
+    at every tile height, and the streaming walk of rounds 1-3 (OGG_MIDAS_TILE_ROWS=0: rows straight from global memory, wave shuffles,
+    mdist from two reductions) -- must give the same BITS on a distorted mesh whose longitudes wrap around, for both area forms and for
+    the angle-only call."""
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1])
+    nj, ni = shape
+    x = np.tile(-300 + np.arange(ni) * 720.0 / max(ni - 1, 1), (nj, 1)) + rng.normal(0, 0.05, shape)     # twice around: mod 360 at work
+    y = np.tile(np.linspace(-89.5, 89.5, nj).reshape(nj, 1), (1, ni)) + rng.normal(0, 0.05, shape)
+    x[0, 0], x[-1, -1] = x[0, 1], x[-1, -2] + 1e-20                                                       # a zero and a tiny difference
+    ref = None
+    for rows in ("0", "1", "2", "4", "6", "8", "12", "99"):
+        monkeypatch.setenv("OGG_MIDAS_TILE_ROWS", rows)
+        got = ogg.generate_grid_metrics_MIDAS(x, y) + ogg.generate_grid_metrics_MIDAS(x, y, latlon_areafix=False)[2:] + (ogg.angle_x(x, y),)
+        if ref is None:
+            ref = got
+            odx, ody, oar = orc.generate_grid_metrics_MIDAS(x, y)
+            assert maxrel(got[0], odx) < 2e-15 and maxrel(got[1], ody) < 2e-15 and maxabs(got[2], oar) <= 5e-12 * np.abs(oar).max()
+            continue
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert np.array_equal(a, b), (rows, k, float(np.abs(a - b).max()))
+
+
 def test_midas_mercator_r8_band(ogg):
     """The HBM-bound kernel at 1/8 degree width (5761 columns), 400 rows."""
     xo, yo = orc.generate_mercator_grid(5760, -66.85954725, 64.05895973, -300.0, 360, 8.0, True, False)
@@ -376,6 +400,38 @@ def test_sin_cos_restatements_equal_the_library(hip):
     x[-sp.numel():] = sp
     for which in (10, 11, 12):
         assert _libm_check(which, x) == 0, which
+
+
+def test_mdist_restatements_equal_numpy_mod(hip, ogg):
+    """mdist (OGG:682-684) from two fma reductions (ogg_math.h mdist) and from ONE (mdist_one: the generic stencil kernel's) against
+    numpy.mod's own definition -- fmod, + 360 where negative -- evaluated on the device: every bit, 4e7 pairs: longitudes of a grid, differences
+    within an ulp of multiples of 360, TINY differences of either sign (-2.8e-14 < d < 0: the exact d + 360 rounds to 360.0 -- numpy's answer,
+    which the retry of round 1-3's pymod360 turned into a negative number), huge ones, infinities and NaNs."""
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(21)
+    n = 40_000_000
+    q = n // 5
+    x = (torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5) * 1440.0
+    y = (torch.rand(n, dtype=torch.float64, device="cuda:0", generator=g) - 0.5) * 1440.0
+    k = torch.randint(-6, 7, (q,), device="cuda:0", generator=g).to(torch.float64)
+    ulps = torch.randint(-2, 3, (q,), device="cuda:0", generator=g).to(torch.float64)
+    y[:q] = x[:q] + 360.0 * k + ulps * 2.0 ** -43                                   # within a few ulp of a multiple of 360 apart
+    e = torch.randint(-1070, -40, (q,), device="cuda:0", generator=g).to(torch.int32)
+    sgn = torch.randint(0, 2, (q,), device="cuda:0", generator=g).to(torch.float64) * 2 - 1
+    tiny = sgn * torch.ldexp(torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) + 1.0, e)
+    x[q:2 * q] = tiny                                                               # tiny differences of either sign (y = 0)
+    y[q:2 * q] = 0.0
+    big = torch.ldexp(torch.rand(q, dtype=torch.float64, device="cuda:0", generator=g) + 1.0, torch.randint(30, 200, (q,), device="cuda:0", generator=g).to(torch.int32))
+    x[2 * q:3 * q] = big * sgn                                                      # up to 2^200 (beyond 1e12: the fmod path)
+    sp = torch.tensor([0.0, -0.0, 360.0, -360.0, 720.0, 1e-20, -1e-20, 2.8e-14, -2.8e-14, -2.9e-14, float("inf"), float("-inf"), float("nan"), 1e12, -1e12],
+                      dtype=torch.float64, device="cuda:0")
+    x[-sp.numel():] = sp
+    y[-sp.numel():] = 0.0
+    for which in (13, 14):
+        assert _libm_check(which, x, y) == 0, which
+    # the host-pointer entry, tiny operands: numpy's values bit for bit
+    a = np.array([1e-20, -1e-20, -2e-14, 2e-14, -3e-14, 5e-324, -5e-324, 359.99999999999994, -359.99999999999994])
+    assert np.array_equal(ogg.mdist(a, 0.0), orc.mdist(a, 0.0)) and np.array_equal(ogg.mdist(0.0, a), orc.mdist(0.0, a))
 
 
 def test_bipolar_mesh_does_not_depend_on_rows_per_workgroup(ogg, monkeypatch):
