@@ -289,18 +289,24 @@ def self_launch(n, argv, timeout=None):
     import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = self_launch_command(n, argv, port)
-    try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
-    except subprocess.TimeoutExpired as exc:
-        sys.stderr.write("bench.py: the %d ranks did not finish within %s s\n" % (n, exc.timeout))
-        return 124
+    for attempt in (0, 1):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        # (the port is free NOW; somebody else may take it before torch.distributed.run binds it: one retry with another port)
+        cmd = self_launch_command(n, argv, port)
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired as exc:
+            sys.stderr.write("bench.py: the %d ranks did not finish within %s s\n" % (n, exc.timeout))
+            return 124
+        sys.stderr.write(p.stderr)
+        if p.returncode == 0 or attempt == 1 or not any(t in p.stderr for t in ("EADDRINUSE", "Address already in use", "address already in use")):
+            break
+        sys.stderr.write("bench.py: the rendezvous port %d was taken between choosing and binding it; once more with another port\n" % port)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     for l in p.stdout.splitlines():
         if not l.startswith("{"):

@@ -258,16 +258,21 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
  * the reference (OGG:583-584), so only orders 2 and 4 are valid.  Band form as for the bipolar cap; cell rows
  * below j0 are simply not evaluated (main() discards the doughnut rows, OGG:1177-1186).
  * arc_form selects how the great-arc distance between two probes of the finite-difference stencil is taken:
- *   OGG_DP_ARC_LITERAL  the reference's arithmetic (haversine of the projected, unwrapped longitudes and latitudes,
- *                       OGG:522-532); the default of every entry point without an arc_form argument;
- *   OGG_DP_ARC_CHORD    same stencil, distance from the gnomonic images of the probes (no atan2 / unwrap): ~7x less arithmetic.
- *                       NOT the reference's arithmetic; opt-in only.
- * Measured against the CPU oracle at full 1/8 degree size (5760 x 560 cap, profiles/dp_parity.json; max relative difference of
- * dx / dy / area): literal 1.3e-9 / 1.2e-9 / 7.6e-10, chord 1.5e-9 / 1.3e-9 / 9.8e-10 -- practically the same, and growing with the
- * resolution for both (7e-12 at Ni = 72): the reference differentiates an arc of 2e-3 index units numerically, so ONE ulp of
- * difference between the device library's atan2 and the host's is amplified by ~Ni / (4e-3 pi).  The literal form is the
- * reference's operation sequence; it is not bit-identical to a CPU run because the transcendental functions are not (the
- * restatements of atan / atan2 used here reproduce the bits of the ROCm 7.2 device library, ogg_libm_check_dev). */
+ *   OGG_DP_ARC_LITERAL  the reference's operation sequence (haversine of the projected, unwrapped longitudes and latitudes,
+ *                       OGG:522-532); what the entry points WITHOUT an arc_form argument run;
+ *   OGG_DP_ARC_CHORD    same stencil, distance from the probes' positions on the sphere (no atan2 / unwrap): ~6x less arithmetic.
+ *                       Not the reference's operation sequence -- and closer to what its formula means (below).  Since round 4 the
+ *                       default of the Python host (main(), displacedPoleCap_metrics_quad, SupergridPlan, bench.py; OGG_DP_ARC).
+ * Measured on the 5760 x 560 cap of BASELINE config 4 (1/8 degree), max relative difference of dx / dy / area
+ *   from the numpy oracle (profiles/dp_parity.json):             literal 1.3e-9 / 1.2e-9 / 7.6e-10   chord 1.5e-9 / 1.3e-9 / 9.8e-10
+ *   from a 50-digit evaluation of the reference's own formula on 10 500 cells (tests/golden/truth_table.npz, tests/test_gpu_truth.py,
+ *   profiles/r04_truth_table.json):   the fp64 reference itself 1.4e-9 / 9.0e-10 / 1.2e-9   literal 1.4e-9 / 8.5e-10 / 1.2e-9
+ *                                     chord 7.6e-10 / 2.7e-10 / 8.3e-10
+ * Both grow with the resolution (7e-12 at Ni = 72): the reference differentiates an arc of 2e-3 index units numerically, so ONE ulp of
+ * atan2 is amplified by ~Ni / (4e-3 pi); the fp64 reference is itself that far from the exact value of its formula, and the chord form,
+ * which never forms a longitude, is the closest of the three.  The literal form is not bit-identical to a CPU run either, because the
+ * transcendental functions are not (the restatements of atan / atan2 used here reproduce the bits of the ROCm 7.2 device library,
+ * ogg_libm_check_dev). */
 /* (OGG_DP_ARC_LITERAL = 0, OGG_DP_ARC_CHORD = 1: defined next to the error codes at the top of this file) */
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                         double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ogg_api.hip", "ogg_axes.hip", "ogg_midas.hip", "ogg_bipolar.hip", "ogg_dpole.hip", "ogg_elementwise.hip", "ogg_latlon_fused.hip", "ogg_pass.hip", "ogg_reduce.hip"]
 HEADERS = ["ogg_common.h", "ogg_math.h", "ogg_bipolar_dev.h", "ogg_dpole_dev.h", "ogg_latlon_fused_dev.h", "../../include/ogg_hip.h"]
 LIB = os.path.join(HERE, "libogg_hip.so")
+HASH_FILE = os.path.join(HERE, "libogg_hip.srchash")   # source hash of the library next to it (a built artefact, git-ignored like the .so)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function"]
 
@@ -43,8 +44,16 @@ def needs_build():
     deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS if os.path.exists(os.path.join(HERE, f))] + [__file__]
     if any(os.path.getmtime(d) > t for d in deps):
         return True
-    try:   # a library built from other sources (a checkout that kept an old .so with fresh mtimes)
-        return source_hash().encode() not in open(LIB, "rb").read()
+    # a library built from other sources (a checkout that kept an old .so with fresh mtimes): the hash build() wrote next to it
+    try:
+        return open(HASH_FILE).read().strip() != source_hash()
+    except OSError:
+        pass
+    try:   # no side file (a library from an older build.py): look for the hash inside the binary, once, and write the side file
+        ok = source_hash().encode() in open(LIB, "rb").read()
+        if ok:
+            open(HASH_FILE, "w").write(source_hash() + "\n")
+        return not ok
     except OSError:
         return True
 
@@ -78,6 +87,7 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout)
+    open(HASH_FILE, "w").write(src_hash + "\n")
     return LIB
 
 

@@ -177,7 +177,16 @@ const char* ogg_last_error(void) { return ogg::g_err; }
 #endif
 // "... src <hash>": the hash of the kernel sources this library was built from (csrc/build.py source_hash()); the counter files under
 // profiles/ carry the hash of the library they were taken with, and bench.py quotes them only when the two agree
-const char* ogg_version(void) { return "ogg_hip 0.3 (gfx950) src " OGG_SRC_HASH; }
+// The restated transcendental functions of ogg_math.h (atan, atan2, asin, sin, cos) reproduce the bits of the device library they were read
+// from: ROCm 7.2.0's ocml.  The string names that release and the HIP version this library was built with, so that a build against another
+// ROCm says so where a user looks first; whether the restatements still agree with the installed library is what ogg_libm_check_dev tests
+// (tests/test_gpu_parity.py, and a short form in __graft_entry__.smoke()).
+#define OGG_STR2(x) #x
+#define OGG_STR(x) OGG_STR2(x)
+const char* ogg_version(void) {
+    return "ogg_hip 0.4 (gfx950; libm restatements read from ROCm 7.2.0 ocml, built with HIP " OGG_STR(HIP_VERSION_MAJOR) "." OGG_STR(HIP_VERSION_MINOR) "." OGG_STR(
+        HIP_VERSION_PATCH) ") src " OGG_SRC_HASH;
+}
 // sizeof of the descriptor structs of the ABI (0: ogg_latlon_band, 1: ogg_bipolar_band), so that a binding can check its layout
 long ogg_abi_sizeof(int which) {
     return which == 0 ? (long)sizeof(ogg_latlon_band)

@@ -343,27 +343,16 @@ __global__ __launch_bounds__(256) void dpole_quad_tables_kernel(DpQuadParams p) 
     dpole_quad_tables_body<N>(p, blockIdx.x, gridDim.x);
 }
 
-#ifndef OGG_DQ_MINWAVES
-#define OGG_DQ_MINWAVES 2
-#endif
 template <int N, int ARC>
-__global__ __launch_bounds__(64 * DQ_WAVES, OGG_DQ_MINWAVES) void dpole_quad_kernel(DpQuadParams p) {
+__global__ __launch_bounds__(64 * DQ_WAVES, 2) void dpole_quad_kernel(DpQuadParams p) {
     __shared__ unsigned s_slot;
     const long t = (ARC == DP_ARC_LITERAL) ? take_ticket(p.ticket, &s_slot) : (long)blockIdx.x;
-#if OGG_DQ_RING == 3
-    if (ARC == DP_ARC_LITERAL) {
-        __shared__ DqLds<(ARC == DP_ARC_LITERAL) ? N : 1> lds;
-        dpole_quad_literal_lds<N>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx, reinterpret_cast<DqLds<N>&>(lds));
-        return;
-    }
-#elif OGG_DQ_RING > 0
     if (ARC == DP_ARC_LITERAL) {
         __shared__ double ring[(ARC == DP_ARC_LITERAL) ? dq_ring_doubles<N>() : 1];
-        dpole_quad_literal_ring<N, OGG_DQ_RING>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx,
-                                                ring + (threadIdx.x >> 6) * (OGG_DQ_RING * dq_ring_slot_doubles<N>()));
+        dpole_quad_literal_ring<N, DQ_RING>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx,
+                                            ring + (threadIdx.x >> 6) * (DQ_RING * dq_ring_slot_doubles<N>()));
         return;
     }
-#endif
     dpole_quad_body<N, ARC>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
 }
 
@@ -371,7 +360,7 @@ __global__ __launch_bounds__(64 * DQ_WAVES, OGG_DQ_MINWAVES) void dpole_quad_ker
 // block-by-block look-back): an independently written second implementation, kept for OGG_DQ_WALK=regs -- the tests require the
 // LDS-pipelined walk to reproduce its bits
 template <int N>
-__global__ __launch_bounds__(64 * DQ_WAVES, OGG_DQ_MINWAVES) void dpole_quad_regs_kernel(DpQuadParams p) {
+__global__ __launch_bounds__(64 * DQ_WAVES, 2) void dpole_quad_regs_kernel(DpQuadParams p) {
     __shared__ unsigned s_slot;
     const long t = take_ticket(p.ticket, &s_slot);
     dpole_quad_body<N, DP_ARC_LITERAL>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);

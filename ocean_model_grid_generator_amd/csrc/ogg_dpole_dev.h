@@ -28,26 +28,14 @@
 #include "ogg_common.h"
 #include "ogg_math.h"
 
-// Build-time knobs of the literal quadrature's LDS-pipelined walk (dpole_quad_literal_ring / _lds below); the defaults are the measured
-// optimum at 1/8 degree (scripts/ab_build.sh + scripts/ab_time.py on one box):
-#ifndef OGG_DQ_RING
-#define OGG_DQ_RING 2       // 2 (1): pending rows in an LDS ring, two (one) rows of slack for the look-back; 3: dpole_quad_literal_lds (one row of
-#endif                      // slack, nothing pending in registers); 0: the register-pipelined walk of dpole_quad_body
-#ifndef OGG_DQ_LEAN
-#define OGG_DQ_LEAN 3       // probes: 0 the library's atan2 / atan; 3 their restatements (the same bits) with the coefficients from OGG_DQ_ATAN;
-#endif                      // 4 dp_point_fast (divisions without scaling, row-wise fallback)
-#ifndef OGG_DQ_ATAN
-#define OGG_DQ_ATAN 3       // arctangent coefficients: 0 literals in the code, 2 a persistent scalar set, 3 a persistent vector set (40 VGPRs)
-#endif
-#ifndef OGG_DQ_ATAN_WAVE
-#define OGG_DQ_ATAN_WAVE 1  // restated atan: the reciprocal of arguments above 1 behind a wave-uniform branch
-#endif
-#ifndef OGG_DQ_PRIO
-#define OGG_DQ_PRIO 2       // wave priority: 2 high until a row's maps are published, low for its second half; 1 by look-back feedback; 0 none
-#endif
-#ifndef OGG_DQ_LB_AT
-#define OGG_DQ_LB_AT 4      // the look-back loads of the row to finish go out after this many of the 2 * order probes of the row being evaluated
-#endif
+// The literal quadrature's LDS-pipelined walk (dpole_quad_literal_ring below) in the ONE configuration that is built, tested and timed: two
+// pending rows in an LDS ring, the probes' arctangents restated with their coefficients in 40 vector registers (the library's bits), wave
+// priority raised until a row's maps are published, the look-back loads of the row to finish issued after 4 of the row's 2 * order probes.
+// What else was built and measured against it on one box -- pending rows in registers, ring depths 1 and 3, scalar and literal
+// coefficient sets, priorities by look-back feedback, divisions without scaling with a row-wise fallback, a rolled probe loop, and the
+// shader-clock profile of the walk -- is recorded in DESIGN.md 4.2 with its numbers (profiles/r03_dq_profile.txt) and no longer in the source.
+constexpr int DQ_RING = 2;        // rows of slack for the look-back = pending rows parked in LDS
+constexpr int DQ_LB_AT = 4;       // the look-back loads go out after this many probes of the row being evaluated
 
 namespace {
 
@@ -116,34 +104,7 @@ OGG_DEV void dp_point(double r, cplx ep, const DpConst& c, const C& atc, double&
     const cplx w = dp_image(r, ep, c);
     lam_raw = atan2_lib(w.im, w.re, atc) * k180Pi;
     const double rw = cabs_np(w);
-#if OGG_DQ_ATAN_WAVE
-    phi = -90 + div_pi180(atan_lib_wave(rw * c.r_joint, atc));
-#else
-    phi = -90 + div_pi180(atan_lib(rw * c.r_joint, atc));
-#endif
-}
-
-// The literal quadrature's leaner forms.  What a cap's probes never feed these functions is left to a wave-uniform fallback instead of being
-// handled per lane by selects and scaling steps: a denominator 1 + conj(z0) z or an image w outside 2^-300 .. 2^300 (Smith's quotient, the
-// quotient of atan2 and numpy's hypot then take the IEEE divisions without v_div_scale / v_div_fmas / v_div_fixup, ogg_math.h), a latitude
-// north of -45 degrees (atan's argument is <= 1 then and nothing is inverted).
-// The same arithmetic with NO branch and no guard of its own: returns whether this lane's operands were outside what the short forms
-// assume; the caller collects that over the probes of a lattice row and re-evaluates the row with dp_point (general arithmetic) when any lane of the
-// wave says so (one ballot per row; never on a cap main() builds).
-template <class C>
-OGG_DEV bool dp_point_fast(double r, cplx ep, const DpConst& c, const C& atc, double& lam_raw, double& phi) {
-    constexpr double lo = 0x1p-300, hi = 0x1p300;
-    const cplx z = {r * ep.re, r * ep.im};
-    const cplx num = {z.re + c.z0r, z.im + c.z0i};
-    const cplx cz = cmul(cplx{c.z0r, -c.z0i}, z);
-    const cplx den = {1 + cz.re, cz.im};
-    const double dmax = fmax(fabs(den.re), fabs(den.im));
-    const cplx w = cdiv_normal(num, den);
-    const double wmax = fmax(fabs(w.re), fabs(w.im));
-    const double v = cabs_np_normal(w) * c.r_joint;
-    lam_raw = atan2_lib_normal(w.im, w.re, atc) * k180Pi;
-    phi = -90 + div_pi180(atan_lib_le1(v, atc));
-    return !((dmax >= lo) && (dmax <= hi) && (wmax >= lo) && (wmax <= hi) && (v <= 1.0));   // (NaNs count as out of range)
+    phi = -90 + div_pi180(atan_lib_wave(rw * c.r_joint, atc));   // (the reciprocal of arguments above 1 behind a wave-uniform branch)
 }
 
 // OGG:527-532 for point0 = (lam0, phi0), point1 = (lam1, phi1) in degrees
@@ -350,14 +311,6 @@ OGG_DEV unsigned lb_resolve(const unsigned long long* row_words, long s, unsigne
     }
     // wider grids than the batch holds (1/16 degree: 732 strips): the rest block by block, as lb_incoming does
     if (s > 64 * LB_BATCH) lb_compose_from(row_words, 64 * LB_BATCH, s, all, err, t0, t1);
-#if OGG_DQ_PRIO == 1
-    // A wave that found everything published was the late one: it goes ahead of its partner on the SIMD for the next row; a wave that
-    // had to poll again is ahead of the strips to its left: it yields.  (Hardware arbitration is oldest-first otherwise.)
-    if (spins > 0)
-        __builtin_amdgcn_s_setprio(0);
-    else
-        __builtin_amdgcn_s_setprio(3);
-#endif
     return t0 & all;
 }
 
@@ -539,14 +492,17 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
 // -- chord form ------------------------------------------------------------------------------------------------------------
 // The reference differentiates great-arc distances numerically (OGG:535-562): h = (8 ds(eps) - ds(2 eps)) / (12 eps), where
 // ds is the haversine distance between two projected points that are ~2e-6 rad apart, formed from longitudes/latitudes in
-// degrees.  That subtraction of two O(1) angles loses 10 digits: against an 80-bit evaluation the reference's own h is
-// accurate to 2e-9 (relative).  The chord form keeps the SAME stencil (the same probe points, the same conformal image w of
-// each probe) but takes the distance between two probes from their positions on the sphere -- from vectors pa, pb along the two
-// points: sin(ds) = |pa x pb| / (|pa| |pb|) -- : no atan2 / atan / hypot per probe, no sin/cos/asin per pair and no longitude at
-// all, hence no unwrap.  Its h is accurate to 8e-10 and differs from a CPU evaluation of the reference's by ~1.5e-9 at 1/8 degree (the
-// literal form: ~1.3e-9, profiles/dp_parity.json), i.e. by less
-// than the reference's own rounding error, but it is NOT the reference's arithmetic: it is an explicit option (arc_form = 1),
-// the literal form is the default everywhere.
+// degrees.  That subtraction of two O(1) angles loses 10 digits.  The chord form keeps the SAME stencil (the same probe points, the same
+// conformal image w of each probe) but takes the distance between two probes from their positions on the sphere -- from vectors pa, pb
+// along the two points: sin(ds) = |pa x pb| / (|pa| |pb|) -- : no atan2 / atan / hypot per probe, no sin/cos/asin per pair and no
+// longitude at all, hence no unwrap.  Against a 50-digit evaluation of the reference's own formula on 10 500 cells of the 1/8 degree cap
+// (tests/golden/truth_table.npz, tests/test_gpu_truth.py, profiles/r04_truth_table.json; max relative error of dx / dy / area):
+//     the fp64 reference itself (numpy)   1.41e-9 / 8.96e-10 / 1.21e-9
+//     the literal form (this file)         1.37e-9 / 8.50e-10 / 1.20e-9
+//     the chord form                       7.61e-10 / 2.74e-10 / 8.26e-10
+// i.e. the chord form is CLOSER to what the reference's formula means than the reference's own fp64 evaluation, at a sixth of the
+// arithmetic.  Since round 4 it is the default of main() and of the Python entry points (OGG_DP_ARC / dp_arc / arc_form = literal opts
+// back into the reference's operation sequence); the C entry points without an arc_form argument keep the literal form.
 // A probe's point on the sphere in homogeneous form: with w = num / den the conformal image of the probe (OGG:454-455),
 // (X, Y) = r_joint w its gnomonic image and (X, Y, -1) a vector along the point, so is
 //   (P, Q, -D) = (r_joint Re(num conj(den)), r_joint Im(num conj(den)), -|den|^2)
@@ -612,18 +568,11 @@ OGG_DEV void dq_probe_pair(int k, const double* r, const cplx* ep, double& ra, d
     }
 }
 
-#ifndef OGG_DQ_PIPELINE
-#define OGG_DQ_PIPELINE 1   // literal form: one-row software pipeline of the look-back (0: finish a row right after its evaluation)
-#endif
-#ifndef OGG_DQ_UNROLL
-#define OGG_DQ_UNROLL 8   // the probe loop fully unrolled (no compare-selects to pick a probe's operands and result slots): 233 VGPRs
-#endif                    // like the rolled loop's 238, 2.0 -> 1.67 ms for config 4; 1 = rolled
-
 // phase 1 of the literal form: all probes of this lane's lattice point (OGG:522-526, 454-466), ONE at a time (two projections
 // in flight need 60 more registers than one)
 template <int F>
 OGG_DEV void dq_literal_probes_lib(const double* r, const cplx* ep, const DpConst& c, DqPending<F>& o) {
-#pragma unroll OGG_DQ_UNROLL
+#pragma unroll    // fully unrolled: no compare-selects to pick a probe's operands and result slots
     for (int q = 0; q < 2 * F; ++q) {
         const int k = q >> 1;
         double ra, rb;
@@ -642,20 +591,12 @@ OGG_DEV void dq_literal_probes_lib(const double* r, const cplx* ep, const DpCons
     }
 }
 
-// the same for the LDS-pipelined walks below (probes Q0 .. Q1-1 of the lattice point), by OGG_DQ_LEAN: 0 the library's atan2 / atan
-// and full IEEE divisions (dq_literal_probes_lib's arithmetic), 3 the restated arctangents with the coefficients from `atc` (the library's
-// bits, ogg_math.h), 4 dp_point_fast (returns whether any probe was outside what it assumes: the caller then re-evaluates the row)
-#if OGG_DQ_ATAN == 3
+// the same for the LDS-pipelined walk below (probes Q0 .. Q1-1 of the lattice point): the restated arctangents with their coefficients in
+// vector registers (`atc`; the library's bits, ogg_math.h)
 typedef AtanVgpr DqAtan;
-#elif OGG_DQ_ATAN == 2
-typedef AtanCoefs DqAtan;
-#else
-typedef AtanLiterals DqAtan;
-#endif
 
 template <int F, int Q0 = 0, int Q1 = 2 * F>
-OGG_DEV bool dq_literal_probes(const double* r, const cplx* ep, const DpConst& c, const DqAtan& atc, DqPending<F>& o) {
-    bool bad = false;
+OGG_DEV void dq_literal_probes(const double* r, const cplx* ep, const DpConst& c, const DqAtan& atc, DqPending<F>& o) {
 #pragma unroll
     for (int q = Q0; q < Q1; ++q) {
         const int k = q >> 1;
@@ -664,37 +605,7 @@ OGG_DEV bool dq_literal_probes(const double* r, const cplx* ep, const DpConst& c
         dq_probe_pair<F>(k, r, ep, ra, rb, epa, epb);
         const bool minus = (q & 1) != 0;
         double v, ph;
-#if OGG_DQ_LEAN == 4
-        bad |= dp_point_fast(minus ? rb : ra, minus ? epb : epa, c, atc, v, ph);
-#elif OGG_DQ_LEAN == 3
         dp_point(minus ? rb : ra, minus ? epb : epa, c, atc, v, ph);
-#else
-        dp_point(minus ? rb : ra, minus ? epb : epa, c, v, ph);
-#endif
-#pragma unroll
-        for (int t = 0; t < F; ++t) {
-            o.va[t] = (q == 2 * t) ? v : o.va[t];
-            o.vb[t] = (q == 2 * t + 1) ? v : o.vb[t];
-            o.pa[t] = (q == 2 * t) ? ph : o.pa[t];
-            o.pb[t] = (q == 2 * t + 1) ? ph : o.pb[t];
-        }
-    }
-    return bad;
-}
-
-// all probes of a lattice point through the general (library) arithmetic: the fallback of OGG_DQ_LEAN == 4.  A rolled loop (one copy of
-// the arithmetic, operands and result slots picked by compare-selects), inline: a call here would make the hot path save registers.
-template <int F>
-OGG_DEV void dq_literal_probes_general(const double* r, const cplx* ep, const DpConst& c, DqPending<F>& o) {
-#pragma unroll 1
-    for (int q = 0; q < 2 * F; ++q) {
-        const int k = q >> 1;
-        double ra, rb;
-        cplx epa, epb;
-        dq_probe_pair<F>(k, r, ep, ra, rb, epa, epb);
-        const bool minus = (q & 1) != 0;
-        double v, ph;
-        dp_point(minus ? rb : ra, minus ? epb : epa, c, v, ph);
 #pragma unroll
         for (int t = 0; t < F; ++t) {
             o.va[t] = (q == 2 * t) ? v : o.va[t];
@@ -711,7 +622,7 @@ template <int F>
 OGG_DEV void dq_literal_finish(const DqPending<F>& o, unsigned st, double reps, double& hi, double& hj) {
     constexpr int H = F / 2;
     double ds[F];
-#pragma unroll OGG_DQ_UNROLL
+#pragma unroll
     for (int k = 0; k < F; ++k) {
         double va = o.va[0], vb = o.vb[0], pha = o.pa[0], phb = o.pb[0];
 #pragma unroll
@@ -756,18 +667,6 @@ OGG_DEV double dq_weight(int k) {  // w[k] of OGG:240 (order 4); order 2 sums th
     return 1.0;
 }
 
-#ifdef OGG_DQ_PROFILE   // experiment build (scripts/ab_build.sh WORK prof -DOGG_DQ_PROFILE=1; scripts/dq_profile_run.py): shader-clock cycles the waves of
-// the literal quadrature spend in (0) the probes of a lattice row, (1) publishing, (2) resolving the look-back, (3) haversines + quadrature
-// sums, [4] = lattice rows, [5] = waves, [6] = whole walk; summed over waves, printed by the host when OGG_DQ_PROFILE is set
-__device__ unsigned long long g_dq_prof[8];
-__device__ unsigned long long g_dq_prof_strip[3][8];   // by eighth of the row (strip position): resolve cycles, iteration cycles, lattice rows
-#define DQ_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
-#define DQ_ADD(slot, a, b) prof[slot] += (b) - (a)
-#else
-#define DQ_TICK(var)
-#define DQ_ADD(slot, a, b)
-#endif
-
 // Strip `strip` of chunk `chunk`: all 64 lanes of the wave call; strip, chunk wave-uniform.
 template <int N, int ARC>
 OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
@@ -808,12 +707,10 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
 #pragma unroll
     for (int k = 0; k < F; ++k) pend.va[k] = pend.vb[k] = pend.pa[k] = pend.pb[k] = 0.0;
     pend_next = pend;
-    // PIPE: row L + 1 is evaluated between publishing row L's maps and reading its predecessors' (the wait is hidden, the pending state
-    // of two rows lives in registers); !PIPE: a row is finished right after its evaluation (half the pending state: one wave more per SIMD
-    // for the literal form at order 4, which then has to hide the wait)
-    constexpr bool PIPE = (OGG_DQ_PIPELINE != 0) || (ARC == DP_ARC_CHORD);
+    // row L + 1 is evaluated between publishing row L's maps and reading its predecessors' (the wait is hidden, the pending state of two
+    // rows lives in registers)
 #pragma unroll 1
-    for (long L = -1; L < (PIPE ? n_lat : n_lat - 1); ++L) {
+    for (long L = -1; L < n_lat; ++L) {
         // ---- evaluate lattice row L + 1 ------------------------------------------------------------------------------
         if (L + 1 < n_lat) {
             const long row = M * r0 + L + 1;      // band-local lattice row
@@ -853,12 +750,8 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
                 if (lane == 63) lb_publish(words + (L + 1) * p.n_strips + strip, f0, f1);
             }
         }
-        if (!PIPE) {
-            pend = pend_next;
-            inc0 = inc0_next, inc1 = inc1_next;
-        }
         // ---- finish lattice row Lf and feed it to the quadrature --------------------------------------------------------
-        const long Lf = PIPE ? L : L + 1;
+        const long Lf = L;
         if (Lf >= 0) {
             double hi, hj;
             if (ARC == DP_ARC_CHORD) {
@@ -903,10 +796,8 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
                 p.dxq[(r0 + nc) * p.g.ni + ci] = qavg_1d<N>(ah) * p.Re;
             }
         }
-        if (PIPE) {
-            pend = pend_next;
-            inc0 = inc0_next, inc1 = inc1_next;
-        }
+        pend = pend_next;
+        inc0 = inc0_next, inc1 = inc1_next;
         chi = pend_next.va[0], chj = pend_next.vb[0];
     }
 }
@@ -914,7 +805,7 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
 // ---- literal form with its pending rows in LDS --------------------------------------------------------------------------------
 // The look-back makes every wave wait for the SLOWEST strip to its left, row by row, and the waves of a SIMD then compute and wait in
 // phase: with one row of slack (dpole_quad_body above: a second pending row in registers) a quarter of a wave's time is such waiting
-// (measured with OGG_DQ_PROFILE: 5.4 k of 23.6 k cycles per lattice row at 1/8 degree, growing from 2.7 k at the left end of a row to 6.5 k
+// (measured with a shader-clock profile of the walk, profiles/r03_dq_profile.txt: 5.4 k of 23.6 k cycles per lattice row at 1/8 degree, growing from 2.7 k at the left end of a row to 6.5 k
 // at the right end; not the latency of the loads -- issuing them early changes nothing).  Here a wave parks what a row's second half needs --
 // raw longitude and latitude of the 2 * order probes, 16 doubles per lane, and its strip-local maps -- in a ring of D slots in LDS
 // instead of registers and finishes row R - D while the strips to its left have had D rows' time to publish it: D = 2 fits the CU
@@ -922,7 +813,7 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
 template <int N>
 constexpr int dq_ring_slot_doubles() { return (4 * N + 1) * 64; }   // [4 F values + the two maps][lane]
 template <int N>
-constexpr int dq_ring_doubles() { return DQ_WAVES * (OGG_DQ_RING > 0 ? OGG_DQ_RING : 1) * dq_ring_slot_doubles<N>(); }
+constexpr int dq_ring_doubles() { return DQ_WAVES * DQ_RING * dq_ring_slot_doubles<N>(); }
 
 template <int F>
 OGG_DEV void dq_literal_finish_ring(const double* slot, unsigned st, double reps, double& hi, double& hj) {   // slot: this lane's column of the slot
@@ -976,10 +867,6 @@ OGG_DEV void dpole_quad_literal_ring(const DpQuadParams& p, long strip, long chu
     double dyc[N], ysum = 0.0, dxv = 0.0;        // quadrature state of the cell row in progress
 #pragma unroll
     for (int k = 0; k < N; ++k) dyc[k] = 0.0;
-#ifdef OGG_DQ_PROFILE
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    DQ_TICK(t_walk0);
     double rn[NV];                                // the radii of the next row to evaluate, loaded one iteration ahead
 #pragma unroll
     for (int v = 0; v < NV; ++v) rn[v] = row_tab[v * p.n_rows + M * r0];
@@ -991,10 +878,7 @@ OGG_DEV void dpole_quad_literal_ring(const DpQuadParams& p, long strip, long chu
         LbBatch lbb;
         DqPending<F> pend;
         unsigned f0 = 0u, f1 = 0u;
-        DQ_TICK(t_a);
-#if OGG_DQ_PRIO == 2
         __builtin_amdgcn_s_setprio(3);   // until the maps are out: other waves wait for them
-#endif
         if (R < n_lat) {
             // ---- evaluate lattice row R, publish its maps ----------------------------------------------------------------------
             const long row = M * r0 + R;
@@ -1004,13 +888,10 @@ OGG_DEV void dpole_quad_literal_ring(const DpQuadParams& p, long strip, long chu
             const long row_n = (R + 1 < n_lat) ? row + 1 : row;
 #pragma unroll
             for (int v = 0; v < NV; ++v) rn[v] = row_tab[v * p.n_rows + row_n];   // ahead of the look-back loads below (results return in order)
-            constexpr int QS = (OGG_DQ_LB_AT < 0) ? 0 : ((OGG_DQ_LB_AT > 2 * F) ? 2 * F : OGG_DQ_LB_AT);
-            bool bad = dq_literal_probes<F, 0, QS>(r, ep, c, atc, pend);
+            constexpr int QS = (DQ_LB_AT > 2 * F) ? 2 * F : DQ_LB_AT;
+            dq_literal_probes<F, 0, QS>(r, ep, c, atc, pend);
             if (Rf >= 0 && strip > 0) lb_issue(words + Rf * p.n_strips, strip, lbb);
-            bad |= dq_literal_probes<F, QS, 2 * F>(r, ep, c, atc, pend);
-#if OGG_DQ_LEAN == 4
-            if (__builtin_expect(__ballot(bad) != 0ull, 0)) dq_literal_probes_general<F>(r, ep, c, pend);
-#endif
+            dq_literal_probes<F, QS, 2 * F>(r, ep, c, atc, pend);
 #pragma unroll
             for (int k = 0; k < F; ++k) {         // maps of this column (OGG:471-474): one bit per probe
                 const double va = pend.va[k], vb = pend.vb[k];
@@ -1033,13 +914,7 @@ OGG_DEV void dpole_quad_literal_ring(const DpQuadParams& p, long strip, long chu
             if (__ballot(f0 != 0u || f1 != ALL) != 0ull) map_scan(f0, f1);
             if (lane == 63) lb_publish(words + R * p.n_strips + strip, f0, f1);
         }
-#if OGG_DQ_PRIO == 2
         __builtin_amdgcn_s_setprio(0);   // the second half of a row is nobody's critical path
-#endif
-        DQ_TICK(t_c);
-#ifdef OGG_DQ_PROFILE
-        if (R < n_lat) prof[1] += t_c - t_a, prof[4] += 1;
-#endif
         if (Rf >= 0) {
             // ---- finish lattice row Rf, parked D iterations ago, and feed it to the quadrature -----------------------------------
             const double* slot = my + (Rf % D) * SLOT;
@@ -1048,11 +923,6 @@ OGG_DEV void dpole_quad_literal_ring(const DpQuadParams& p, long strip, long chu
                 if (R >= n_lat) lb_issue(words + Rf * p.n_strips, strip, lbb);
                 s_in = lb_resolve(words + Rf * p.n_strips, strip, ALL, lbb, err);
             }
-#ifdef OGG_DQ_PROFILE
-            asm volatile("" ::"s"(s_in));
-            DQ_TICK(t_d);
-            DQ_ADD(2, t_c, t_d);
-#endif
             const unsigned long long mw = __double_as_longlong(slot[4 * F * 64]);
             const unsigned inc0 = (unsigned)(mw & 0xffffull), inc1 = (unsigned)((mw >> 16) & 0xffffull);
             double hi, hj;
@@ -1102,203 +972,6 @@ OGG_DEV void dpole_quad_literal_ring(const DpQuadParams& p, long strip, long chu
                 slot[(2 * F + k) * 64] = pend.pa[k], slot[(3 * F + k) * 64] = pend.pb[k];
             }
             slot[4 * F * 64] = __longlong_as_double((long long)((unsigned long long)f0 | ((unsigned long long)f1 << 16)));
-        }
-#ifdef OGG_DQ_PROFILE
-        DQ_TICK(t_e);
-        DQ_ADD(7, t_a, t_e);
-        DQ_ADD(3, t_c, t_e);
-#endif
-    }
-    atc.keep();
-#ifdef OGG_DQ_PROFILE
-    if (lane == 0) {
-        DQ_TICK(t_walk1);
-        prof[6] = t_walk1 - t_walk0, prof[5] = 1;
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_dq_prof[k], prof[k]);
-        const int bucket = (int)((strip * 8) / p.n_strips);
-        atomicAdd(&g_dq_prof_strip[0][bucket], prof[2]);
-        atomicAdd(&g_dq_prof_strip[1][bucket], prof[7]);
-        atomicAdd(&g_dq_prof_strip[2][bucket], prof[4]);
-    }
-#endif
-}
-
-// ---- literal form, nothing pending in registers ------------------------------------------------------------------------------------
-// The same walk with ONE row of slack, for the register file: a probe's longitude and latitude go to the row's LDS slot the moment they
-// exist (two slots per wave: the row being evaluated and the row waiting for its look-back), its two map bits are taken at once (they
-// need the left neighbour's longitude of the SAME probe only), and the row radii of the chunk -- wave-uniform, the same for the four
-// strips of a workgroup -- sit in LDS once per workgroup instead of in ten vector registers per wave.  That leaves room for the
-// arctangent coefficients in vector registers and for the short forms of the divisions (dp_point_fast) without spills.
-template <int N>
-struct DqLds {
-    double ring[DQ_WAVES][2][4 * N + 1][64];          // [wave][slot][2 F longitudes, 2 F latitudes, the maps][lane]
-    double rows[N + 1][(N - 1) * DQ_RPC_MAX + 1];      // [row variant][lattice row of the chunk]: gnomonic radii
-};
-
-template <int N>
-OGG_DEV void dpole_quad_literal_lds(const DpQuadParams& p, long strip, long chunk, DqLds<N>& lds) {
-    constexpr int M = N - 1, F = N, NV = F + 1, H = F / 2;
-    constexpr unsigned ALL = (1u << (2 * F)) - 1u;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long r0 = chunk * p.rows_per_chunk;
-    const long nc = (p.n_cell_rows - r0 < p.rows_per_chunk) ? p.n_cell_rows - r0 : p.rows_per_chunk;
-    const long n_lat = M * nc + 1;
-    {   // the chunk's row radii, once per workgroup (all four waves: before any of them may leave)
-        const double* __restrict__ row_tab = p.row_tab;
-        for (int k = threadIdx.x; k < NV * (int)n_lat; k += 64 * DQ_WAVES) {
-            const int v = k / (int)n_lat, L = k % (int)n_lat;
-            lds.rows[v][L] = row_tab[v * p.n_rows + M * r0 + L];
-        }
-        __syncthreads();
-    }
-    const long u0 = strip * DQ_COLS;
-    if (u0 >= p.n_cols - 1) return;              // wave-uniform
-    const long u = u0 + lane;
-    const bool valid = u < p.n_cols;
-    const long uc = valid ? u : p.n_cols - 1;
-    const long ci = uc / M;
-    const bool cell_start = valid && (uc % M == 0);
-    const bool out_lane = cell_start && ci < p.g.ni && lane <= 63 - M;
-    const bool dy_edge = cell_start && ci == p.g.ni;
-    const DpConst c = dp_const(p.g);
-    const double reps = 1.0 / p.eps;
-    const double* __restrict__ col_tab = p.col_tab;
-    cplx ep[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ep[v] = cplx{col_tab[(v * 2 + 0) * p.n_cols + uc], col_tab[(v * 2 + 1) * p.n_cols + uc]};
-    const bool own_top = (p.n_dx_rows > p.n_cell_rows) && (r0 + nc == p.n_cell_rows);
-    unsigned long long* words = p.words + (chunk * (M * p.rows_per_chunk + 1)) * p.n_strips;
-    int* err = (int*)(p.ticket + 1);
-    double* my = &lds.ring[wave][0][0][lane];
-    constexpr int SLOT = (4 * F + 1) * 64;
-    // column 0 is compared with lon_grid[0,0] of its probe mesh (OGG:463): the seeds of the i-variants
-    const double i_first = lattice_node(p.q, 0, 0);
-
-    double dyc[N], ysum = 0.0, dxv = 0.0;        // quadrature state of the cell row in progress
-#pragma unroll
-    for (int k = 0; k < N; ++k) dyc[k] = 0.0;
-    DqAtan atc;
-    atc.load(kAtanRed);
-#pragma unroll 1
-    for (long R = 0; R <= n_lat; ++R) {
-        const long Rf = R - 1;                    // the row finished in this iteration
-        LbBatch lbb;
-#if OGG_DQ_PRIO == 2
-        __builtin_amdgcn_s_setprio(3);   // until the maps are out: other waves wait for them
-#endif
-        if (R < n_lat) {
-            // ---- evaluate lattice row R probe by probe into its slot, take its maps, publish them --------------------------------
-            double* slot = my + (R & 1) * SLOT;
-            unsigned f0 = 0u, f1 = 0u;
-            bool bad = false;
-            auto emit = [&](int q, double v, double ph) {       // q = 2 k + (0: the "+" probe of pair k, 1: the "-" probe)
-                const int k = q >> 1;
-                slot[((q & 1) * F + k) * 64] = v;
-                slot[((2 + (q & 1)) * F + k) * 64] = ph;
-                const double pv = wave_prev(v);
-                bool m0, m1;
-                if (u == 0) {
-                    const double off = (k < H) ? (double)(k + 1) * p.eps : 0.0;
-                    const double seed = p.g.lon0 + (((q & 1) ? i_first - off : i_first + off) * 360.0) / (double)p.g.ni;
-                    m0 = m1 = (v - seed > 100);
-                } else {
-                    m0 = (v - pv > 100), m1 = (v - (pv - 360) > 100);   // previous column not lowered / lowered (OGG:473-474)
-                }
-                f0 |= (m0 ? 1u : 0u) << q;
-                f1 |= (m1 ? 1u : 0u) << q;
-            };
-            constexpr int QS = (OGG_DQ_LB_AT < 0) ? 0 : ((OGG_DQ_LB_AT > 2 * F) ? 2 * F : OGG_DQ_LB_AT);
-#pragma unroll
-            for (int q = 0; q < 2 * F; ++q) {
-                if (q == QS && Rf >= 0 && strip > 0) lb_issue(words + Rf * p.n_strips, strip, lbb);
-                const int k = q >> 1;
-                // variant of the row radius / of e' (0: base, 2m-1: +m eps, 2m: -m eps): pair k < H moves the column, pair k >= H the row
-                const int vcol = (k < H) ? 2 * (k + 1) - 1 + (q & 1) : 0;
-                const int vrow = (k >= H) ? 2 * (k - H + 1) - 1 + (q & 1) : 0;
-                const double rr = lds.rows[vrow][R];
-                double v, ph;
-#if OGG_DQ_LEAN == 4
-                bad |= dp_point_fast(rr, ep[vcol], c, atc, v, ph);
-#elif OGG_DQ_LEAN == 3
-                dp_point(rr, ep[vcol], c, atc, v, ph);
-#else
-                dp_point(rr, ep[vcol], c, v, ph);
-#endif
-                emit(q, v, ph);
-            }
-#if OGG_DQ_LEAN == 4
-            if (__builtin_expect(__ballot(bad) != 0ull, 0)) {   // operands the short forms do not cover: the whole row again, general arithmetic
-                f0 = f1 = 0u;
-#pragma unroll 1
-                for (int q = 0; q < 2 * F; ++q) {
-                    const int k = q >> 1;
-                    const int vcol = (k < H) ? 2 * (k + 1) - 1 + (q & 1) : 0;
-                    const int vrow = (k >= H) ? 2 * (k - H + 1) - 1 + (q & 1) : 0;
-                    cplx e = ep[0];
-#pragma unroll
-                    for (int t = 1; t < NV; ++t) e = (vcol == t) ? ep[t] : e;
-                    double v, ph;
-                    dp_point(lds.rows[vrow][R], e, c, v, ph);
-                    emit(q, v, ph);
-                }
-            }
-#endif
-            // lane 0's column belongs to the strip on the left (its state is the incoming state); columns past the row end: identity
-            if ((lane == 0 && u != 0) || !valid) f0 = 0u, f1 = ALL;
-            if (__ballot(f0 != 0u || f1 != ALL) != 0ull) map_scan(f0, f1);
-            slot[4 * F * 64] = __longlong_as_double((long long)((unsigned long long)f0 | ((unsigned long long)f1 << 16)));
-            if (lane == 63) lb_publish(words + R * p.n_strips + strip, f0, f1);
-        }
-#if OGG_DQ_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);   // the second half of a row is nobody's critical path
-#endif
-        if (Rf >= 0) {
-            // ---- finish lattice row Rf and feed it to the quadrature ------------------------------------------------------------
-            const double* slot = my + (Rf & 1) * SLOT;
-            unsigned s_in = 0u;
-            if (strip > 0) {
-                if (R >= n_lat) lb_issue(words + Rf * p.n_strips, strip, lbb);
-                s_in = lb_resolve(words + Rf * p.n_strips, strip, ALL, lbb, err);
-            }
-            const unsigned long long mw = __double_as_longlong(slot[4 * F * 64]);
-            const unsigned inc0 = (unsigned)(mw & 0xffffull), inc1 = (unsigned)((mw >> 16) & 0xffffull);
-            double hi, hj;
-            dq_literal_finish_ring<F>(slot, map_apply(inc0, inc1, s_in), reps, hi, hj);
-            const long k = Rf / M;                // cell row of the chunk this lattice row is the row jj of
-            const int jj = (int)(Rf % M);
-            const double pr = hi * hj;            // OGG:589
-            double ah[N], ap[N];
-            ah[0] = hi, ap[0] = pr;
-#pragma unroll
-            for (int i = 1; i < N; ++i) ap[i] = wave_next(ap[i - 1]);
-#pragma unroll
-            for (int i = 1; i < N; ++i) ah[i] = (jj == 0) ? wave_next(ah[i - 1]) : 0.0;
-            if (jj == 0 && k > 0) {               // top edge of cell row k - 1: its last Lobatto row
-#pragma unroll
-                for (int i = 0; i < N; ++i) ysum = ysum + dq_weight<N>(i) * dq_weight<N>(M) * ap[i];   // OGG:244 / 231
-                dyc[M] = hj;
-                const long out_r = r0 + k - 1;
-                const double d = (N == 2) ? (1.0 / 2.0) : (1.0 / 12.0);
-                if (out_lane) {
-                    p.dxq[out_r * p.g.ni + ci] = dxv;
-                    p.dyq[out_r * (p.g.ni + 1) + ci] = qavg_1d<N>(dyc) * p.Re;                        // OGG:595,599
-                    p.daq[out_r * p.g.ni + ci] = (d * d * ysum) * p.Re * p.Re;                        // OGG:597
-                }
-                if (dy_edge) p.dyq[out_r * (p.g.ni + 1) + p.g.ni] = qavg_1d<N>(dyc) * p.Re;
-            }
-            if (k < nc) {
-                if (jj == 0) {
-                    dxv = qavg_1d<N>(ah) * p.Re;                                                       // OGG:594,598
-                    ysum = 0.0;
-                }
-                const double wj = dq_weight<N>(jj);
-#pragma unroll
-                for (int i = 0; i < N; ++i) ysum = ysum + dq_weight<N>(i) * wj * ap[i];
-#pragma unroll
-                for (int q = 0; q < N; ++q) dyc[q] = (jj == q) ? hj : dyc[q];
-            } else if (own_top && out_lane) {     // the j = ny lattice row, dxq only
-                p.dxq[(r0 + nc) * p.g.ni + ci] = qavg_1d<N>(ah) * p.Re;
-            }
         }
     }
     atc.keep();

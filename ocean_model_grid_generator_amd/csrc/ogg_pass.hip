@@ -37,10 +37,6 @@
 
 extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows);
 
-#ifndef OGG_PASS_NEXT_TABLES
-#define OGG_PASS_NEXT_TABLES 1
-#endif
-
 namespace {
 
 constexpr int PASS_TX = 256;
@@ -151,46 +147,20 @@ struct PassBParams {
 // roles of launch B's workgroups; PassBParams::order lists them in dispatch order
 enum { ROLE_BP_MESH = 0, ROLE_DP_MESH, ROLE_BP_GUARD, ROLE_BP_FAST, ROLE_DP_QUAD, N_ROLES };
 
-#ifdef OGG_PASS_TIMELINE   // experiment build (scripts/ab_build.sh WORK tl -DOGG_PASS_TIMELINE=1; scripts/timeline_run.py): first start and
-// last end of every role of launch B in 10 ns ticks (s_memrealtime), printed by the host when OGG_TIMELINE is set
-__device__ unsigned long long g_tl_min[8], g_tl_max[8];
-struct TlScope {
-    int role;
-    __device__ TlScope() : role(7) {
-        if (threadIdx.x == 0) atomicMin(&g_tl_min[7], __builtin_amdgcn_s_memrealtime());
-    }
-    __device__ ~TlScope() {
-        __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&g_tl_max[role], __builtin_amdgcn_s_memrealtime());
-    }
-    __device__ void set(int r) {
-        role = r;
-        if (threadIdx.x == 0) atomicMin(&g_tl_min[r], __builtin_amdgcn_s_memrealtime());
-    }
-};
-#endif
 
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ PassLds lds;
     __shared__ unsigned s_slot;
     __shared__ int s_claim;
-#ifdef OGG_PASS_TIMELINE
-    TlScope tl;
-#endif
     long b = blockIdx.x;
-#if OGG_PASS_NEXT_TABLES
     if (b >= (long)gridDim.x - a.n_next) {   // (n_next = 0: never)
         pass_table_roles<N>(*a.next, b - ((long)gridDim.x - a.n_next));
         return;
     }
-#endif
     const long first_help = (long)gridDim.x - a.n_next - a.share.n_help;
     const bool helper = b >= first_help;
     if (b < a.share.n_wg || helper) {
-#ifdef OGG_PASS_TIMELINE
-        tl.set(helper ? 6 : 5);
-#endif
         if (helper) {
             // helper k of the launch takes the block of a resident workgroup on ITS XCD (workgroup b runs on XCD b % 8)
             const long k = b - first_help, n = a.share.n_wg;
@@ -216,9 +186,6 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
                 b -= n;
         }
     }
-#ifdef OGG_PASS_TIMELINE
-    if (role >= 0) tl.set(role);
-#endif
     if (role == ROLE_BP_MESH) {
         bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
     } else if (role == ROLE_DP_MESH) {   // work item from the ticket, not from the workgroup index: see ogg_dpole_dev.h
@@ -239,24 +206,14 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     }
 }
 
-#ifndef OGG_DQ_MINWAVES_PASS
-#define OGG_DQ_MINWAVES_PASS 2
-#endif
-// launch D: the displaced-pole quadrature in the reference's literal arithmetic (238 VGPRs: its own launch)
+// launch D: the displaced-pole quadrature in the reference's literal arithmetic (256 VGPRs, 70 KB of LDS: its own launch)
 template <int N>
-__global__ __launch_bounds__(PASS_TX, OGG_DQ_MINWAVES_PASS) void pass_d_kernel(DpQuadParams p) {
+__global__ __launch_bounds__(PASS_TX, 2) void pass_d_kernel(DpQuadParams p) {
     __shared__ unsigned s_slot;
     const long t = take_ticket(p.ticket, &s_slot);
-#if OGG_DQ_RING == 3
-    __shared__ DqLds<N> lds;
-    dpole_quad_literal_lds<N>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx, lds);
-#elif OGG_DQ_RING > 0
     __shared__ double ring[dq_ring_doubles<N>()];
-    dpole_quad_literal_ring<N, OGG_DQ_RING>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx,
-                                            ring + (threadIdx.x >> 6) * (OGG_DQ_RING * dq_ring_slot_doubles<N>()));
-#else
-    dpole_quad_body<N, DP_ARC_LITERAL>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx);
-#endif
+    dpole_quad_literal_ring<N, DQ_RING>(p, (t % p.gx) * DQ_WAVES + (threadIdx.x >> 6), t / p.gx,
+                                        ring + (threadIdx.x >> 6) * (DQ_RING * dq_ring_slot_doubles<N>()));
 }
 
 long env_long(const char* name, long dflt) {
@@ -450,14 +407,6 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
     }
     if (int e = mark(1)) return e;
     if (P.launch_b) {
-#ifdef OGG_PASS_TIMELINE
-        {
-            unsigned long long mn[8], mx[8];
-            for (int k = 0; k < 8; ++k) mn[k] = ~0ull, mx[k] = 0ull;
-            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_min), mn, sizeof(mn)));
-            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_max), mx, sizeof(mx)));
-        }
-#endif
         if (next && n_next > 0) {
             PassBParams b = P.B;
             b.next = next, b.n_next = n_next;
@@ -466,17 +415,6 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
             pass_b_kernel<N><<<P.nb, PASS_TX, 0, st>>>(P.B);
         }
         OGG_LAUNCH_CHECK();
-#ifdef OGG_PASS_TIMELINE
-        if (getenv("OGG_TIMELINE")) {
-            OGG_HIP_CHECK(hipStreamSynchronize(st));
-            unsigned long long mn[8], mx[8];
-            OGG_HIP_CHECK(hipMemcpyFromSymbol(mn, HIP_SYMBOL(g_tl_min), sizeof(mn)));
-            OGG_HIP_CHECK(hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_tl_max), sizeof(mx)));
-            static const char* nm[8] = {"bp_mesh", "dp_mesh", "bp_guard", "bp_fast", "dp_quad", "latlon", "ll_help", "any"};
-            for (int k = 0; k < 8; ++k)
-                if (mx[k]) fprintf(stderr, "timeline %-8s first start %8.1f us  last end %8.1f us\n", nm[k], (double)(mn[k] - mn[7]) * 0.01, (double)(mx[k] - mn[7]) * 0.01);
-        }
-#endif
     }
     if (int e = mark(2)) return e;
     if (P.have_quad) {
@@ -484,35 +422,11 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
     }
     if (int e = mark(3)) return e;
     if (P.dq_literal) {
-#ifdef OGG_DQ_PROFILE
-        {
-            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dq_prof), z, sizeof(z)));
-            unsigned long long z3[3][8] = {};
-            OGG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dq_prof_strip), z3, sizeof(z3)));
-        }
-#endif
         if (P.dq_order == 2)
             pass_d_kernel<2><<<P.nd, PASS_TX, 0, st>>>(P.dq);
         else
             pass_d_kernel<4><<<P.nd, PASS_TX, 0, st>>>(P.dq);
         OGG_LAUNCH_CHECK();
-#ifdef OGG_DQ_PROFILE
-        if (getenv("OGG_DQ_PROFILE")) {
-            OGG_HIP_CHECK(hipStreamSynchronize(st));
-            unsigned long long v[8];
-            OGG_HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dq_prof), sizeof(v)));
-            const double w = (double)v[5], rows = (double)v[4];
-            fprintf(stderr, "dq profile: %.0f waves, %.1f lattice rows per wave; cycles per lattice row: probes %.0f, probes + maps + publish %.0f, look-back resolve %.0f, "
-                            "resolve + haversines + sums %.0f, whole iteration %.0f; walk %.0f cycles per wave\n", w, rows / w, (double)v[0] / rows,
-                    (double)v[1] / rows, (double)v[2] / rows, (double)v[3] / rows, (double)v[7] / rows, (double)v[6] / w);
-            unsigned long long b[3][8];
-            OGG_HIP_CHECK(hipMemcpyFromSymbol(b, HIP_SYMBOL(g_dq_prof_strip), sizeof(b)));
-            fprintf(stderr, "  by eighth of the row, resolve / iteration cycles per lattice row:");
-            for (int k = 0; k < 8; ++k) fprintf(stderr, "  %.0f / %.0f", (double)b[0][k] / (double)b[2][k], (double)b[1][k] / (double)b[2][k]);
-            fprintf(stderr, "\n");
-        }
-#endif
     }
     return mark(4);
 }
@@ -618,7 +532,7 @@ int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, doubl
                     const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, PassPipe& H) {
     if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap, south_cap, H.slot[0])) return e;
     // without launch B, launch A writes the outputs themselves: nothing to carry
-    if (!OGG_PASS_NEXT_TABLES || env_long("OGG_PASS_SLOTS", 2) < 2 || !H.slot[0].launch_b || H.slot[0].na == 0) return OGG_OK;
+    if (env_long("OGG_PASS_SLOTS", 2) < 2 || !H.slot[0].launch_b || H.slot[0].na == 0) return OGG_OK;
     OGG_HIP_CHECK(hipGetDevice(&H.device));
     const bool have_cap = cap && cap->n_pt_rows > 0 && cap->workspace, have_dp = south_cap && south_cap->n_pt_rows > 0;
     H.n_slots = 2;   // from here on ~PassPipe frees what has been allocated
