@@ -71,6 +71,14 @@ def test_n_ranks_rehearsed_on_one_gpu(n, workload):
     assert sorted(r["rank"] for r in many["per_rank"]) == list(range(n)) and all(r["ms_per_step"] > 0 for r in many["per_rank"])
     assert "error" not in many["field_checksums"] and many["field_checksums"] == one["field_checksums"]
     assert many["config"]["cells"] == one["config"]["cells"] and many["scaling"] == "strong"
+    # `value` = the slowest rank's own K passes (max over ranks); the same region through a closing barrier is reported beside it
+    assert many["ms_per_step"] == many["ms_per_step_slowest_rank"] == pytest.approx(max(r["ms_per_step"] for r in many["per_rank"]), rel=1e-9)
+    assert many["ms_per_step_with_closing_barrier"] >= many["ms_per_step"] > 0
+    assert abs(many["value"] - many["config"]["cells"] / (many["ms_per_step"] * 1e-3)) < 1e-6 * many["value"]
+    # the band split came from rank 0's own timings on this box, broadcast to the others
+    bs = many["band_split"]
+    assert bs and "measured by rank 0" in bs["source"] and 0 < bs["tail_us"] < bs["pass_us"]
+    assert one["band_split"] is None or "fitted constants" in one["band_split"]["source"]
     assert many["self_check_metrics_error_percent"] and "error" not in many["self_check_metrics_error_percent"]
     for name, errs in many["self_check_metrics_error_percent"].items():
         for a, b in zip(errs, one["self_check_metrics_error_percent"][name]):
