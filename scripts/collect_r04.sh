@@ -4,6 +4,7 @@
 #   b: r8 (the same + the CPU baseline)
 #   c: r8_latdp and r4_om4 in the default (chord) arc form, then their literal-form bench lines
 #   d: the stencil pipeline (bench line, kernel stats, counters), r2 bench line, main() timing
+#   c2: VALU counters of the literal displaced-pole form
 #   e: rank sweeps (r8, r8_latdp, r16)
 part=$1
 tag=r04
@@ -14,6 +15,10 @@ b) scripts/collect_round.sh $tag r8 ;;
 c)
   scripts/collect_round.sh $tag r8_latdp r4_om4 || exit 1
   for wl in r8_latdp r4_om4; do python3 bench.py --workload $wl --dp-arc literal --cpu-sample-div 0 > profiles/${tag}_bench_${wl}_literal.json 2> gpurun_out/bench_${tag}_${wl}_literal.err || exit 1; done
+  ;;
+c2)  # counters of the literal arc form (opt-in since round 4), then its bench line again so that it quotes them
+  scripts/valu_counters.sh ${tag}_literal r8_latdp --dp-arc literal > gpurun_out/valu_${tag}_literal.log 2>&1 || exit 1
+  python3 bench.py --workload r8_latdp --dp-arc literal --cpu-sample-div 0 > profiles/${tag}_bench_r8_latdp_literal.json 2> gpurun_out/bench_${tag}_r8_latdp_literal.err || exit 1
   ;;
 d)
   python3 bench.py --workload r2 --cpu-sample-div 0 > profiles/${tag}_bench_r2.json 2> gpurun_out/bench_${tag}_r2.err || exit 1

@@ -221,9 +221,11 @@ def test_bipolar_cap_mesh(ogg, fvec, Ni, Nj, lat0):
     ill[-1, :] = True                                         # the fold row through the two poles
     record("bp_mesh_%d" % Ni, x_all=float(d.max()), x_regular=float(d[~ill].max()), y=maxabs(phis, op),
            frac_x_gt_1e12=float((d > 1e-12).mean()))
-    assert d[~ill].max() < TOL_COORD and d.max() < TOL_COORD_ILL
+    # north_star's 1e-12 degrees at EVERY point, the symmetry meridians and the two pole points included (measured: x <= 8.8e-13 at 1/16
+    # degree, y <= 2.8e-14; rounds 1-2 needed 2e-11 / 1e-6 at those points, before asin / acos were restated from the library)
+    assert d.max() < TOL_COORD
     dy_ = np.abs(phis - op)
-    assert dy_[:-2].max() < TOL_COORD and dy_.max() < 1e-6   # the two pole points: acos at A -> 1 (App. C: 2e-7)
+    assert dy_.max() < TOL_COORD
     assert maxrel(hi, ohi) < 1e-11 and maxrel(hj, ohj) < 1e-11
     if Ni == 48:
         assert maxabs(lams, fvec["bpm_lams"]) < TOL_COORD_ILL and maxabs(phis, fvec["bpm_phis"]) < TOL_COORD_ILL
