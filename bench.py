@@ -391,8 +391,8 @@ def main():
     if os.environ.get("OGG_SPLIT_CALIBRATE", "1") != "0":
         if args.as_rank is not None and args.as_world > 1:
             plan.calibrate_split(device, rank=0, world=args.as_world, broadcast=False)
-        elif world > 1:
-            plan.calibrate_split(device, rank=rank, world=world)
+        elif world > 1 or use_dist:   # (use_dist at world 1 = OGG_FORCE_DIST: the same calls over RCCL on a one-GPU box)
+            plan.calibrate_split(device, rank=rank, world=world, force=True)
     if args.as_rank is not None:  # single-GPU rehearsal of one rank's share
         sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device=device, halo="recompute", latlon=args.latlon)
     else:

@@ -263,22 +263,25 @@ class SupergridPlan(object):
             s.tail_us, s.pass_us = float(tail_us), float(pass_us)
         self.split_times = {"tail_us": float(tail_us), "pass_us": float(pass_us), "source": source}
 
-    def calibrate_split(self, device, rank=0, world=1, passes=40, broadcast=True):
-        """Replace the fitted split constants by a measurement on THIS box, before any band buffer exists: rank 0 runs the whole grid
-        as one rank (`passes` timed passes after 30 warm ones: pass_us; five more with the library's launch events: the fix-up launch,
-        tail_us) and broadcasts the two numbers; every rank then derives the same edges from them.  Needs a GPU on rank 0 and, for
+    def calibrate_split(self, device, rank=0, world=1, passes=40, broadcast=True, force=False):
+        """Replace the fitted split constants by a measurement on THIS box, before any band buffer exists (rank 0 alone works, a few
+        hundred passes; the others wait in the broadcast): rank 0 runs the whole grid
+        as one rank (`passes` timed passes after 100 warm ones: pass_us; eight more with the library's launch events: the fix-up launch
+        less the cost of an event record, a first guess of tail_us; then, twice, the shares of a middle rank and of the last rank under the
+        current split, from which the tail follows as T_last - cap * T_middle and pass_us as world * T_middle) and broadcasts the two numbers; every rank then derives the same edges from them.  Needs a GPU on rank 0 and, for
         world > 1 with ``broadcast``, an initialised process group.  Returns ``split_times`` (None when the split has no such term:
-        one rank, no bipolar cap, --skip_metrics).  OGG_TOP_RANK_TAIL_US in the environment still overrides the tail time."""
+        one rank, no bipolar cap, --skip_metrics).  OGG_TOP_RANK_TAIL_US in the environment still overrides the tail time.  ``force``: measure
+        and broadcast at world size 1 too (bench.py under OGG_FORCE_DIST=1: the RCCL broadcast on a one-GPU box)."""
         import os
         import time
-        if world <= 1 or self.split_times is None:
+        if (world <= 1 and not force) or self.split_times is None:
             return self.split_times
         vals = [None]
         if rank == 0:
             import torch
             g = Supergrid(self, rank=0, world=1, device=device, halo="recompute")
             g.launch, g.overlap = "pass", False
-            for _ in range(30):
+            for _ in range(100):      # the clocks of a fresh process take ~30 ms to ramp
                 g.run_pass()
             torch.cuda.synchronize(g.device)
             t0 = time.perf_counter()
@@ -286,23 +289,67 @@ class SupergridPlan(object):
                 g.run_pass()
             torch.cuda.synchronize(g.device)
             pass_us = (time.perf_counter() - t0) / passes * 1e6
-            g.reserve_pass_events(5)
+            g.reserve_pass_events(8)
             g.pass_events = []
-            for _ in range(5):
+            for _ in range(8):
                 g.run_pass()
             tail_us = g.pass_launch_times_ms()["pass_tail"]["ms"] * 1e3
             g.pass_events = None
+            # an interval between two event records holds the records' own cost besides the launch: two records back to back
+            # measure it (~3 us), and what is left is what the fix-up launch adds to a pass
+            st = g._stream()
+            ev = g._new_events()
+            gap = []
+            for _ in range(8):
+                L.call("ogg_event_record", ev[0], st)
+                L.call("ogg_event_record", ev[1], st)
+                L.call("ogg_stream_synchronize", st)
+                ms = ctypes.c_float()
+                L.call("ogg_event_elapsed_ms", ev[0], ev[1], ctypes.byref(ms))
+                gap.append(ms.value * 1e3)
+            for k in range(5):
+                L.call("ogg_event_destroy", ev[k])
+            tail_us = max(tail_us - min(gap), 1.0)
+            # ... which is a first guess only: what the last rank pays for its extra launch is the kernel AND the launch's own latency
+            # behind launch B.  Two refinements with the split itself: time the share of a middle rank and of the last rank under the
+            # current split (on this one GPU, one after the other) and take the tail from T_last = cap * T_middle + tail.
+            def share_us(r):
+                h = Supergrid(self, rank=r, world=world, device=device, halo="recompute")
+                h.launch, h.overlap = "pass", False
+                for _ in range(60):
+                    h.run_pass()
+                torch.cuda.synchronize(h.device)
+                t1 = time.perf_counter()
+                for _ in range(150):
+                    h.run_pass()
+                torch.cuda.synchronize(h.device)
+                dt = (time.perf_counter() - t1) / 150 * 1e6
+                h.close()
+                return dt
+
+            first_guess = tail_us
+            if not os.environ.get("OGG_TOP_RANK_TAIL_US"):
+                for _ in range(2):
+                    self.set_split_times(tail_us, pass_us, "calibrating")
+                    t_mid, t_top = share_us((world - 1) // 2), share_us(world - 1)
+                    cap = 1.0 - world * tail_us / pass_us if world * tail_us / pass_us <= 0.5 else 1.0
+                    tail_us = min(max(t_top - cap * t_mid, 0.5 * first_guess), 4.0 * first_guess)
+                    pass_us = world * t_mid
             g.close()
             del g
             torch.cuda.empty_cache()
             if os.environ.get("OGG_TOP_RANK_TAIL_US"):
                 tail_us = float(os.environ["OGG_TOP_RANK_TAIL_US"])
             vals = [(tail_us, pass_us)]
-        if broadcast:
+        if broadcast:   # two doubles from rank 0: a device tensor over RCCL, through the host where the group is gloo (as all_reduce does)
+            import torch
             import torch.distributed as dist
-            dist.broadcast_object_list(vals, src=0)
+            on_gpu = dist.get_backend() != "gloo"
+            t = torch.tensor(list(vals[0]) if rank == 0 else [0.0, 0.0], dtype=torch.float64, device=(device if on_gpu else "cpu"))
+            dist.broadcast(t, src=0)
+            vals = [tuple(float(v) for v in t.tolist())]
         tail_us, pass_us = vals[0]
-        self.set_split_times(tail_us, pass_us, "measured by rank 0 at plan build (%d passes of the whole grid on one GPU; launch events of 5 more)" % passes)
+        self.set_split_times(tail_us, pass_us, "measured by rank 0 at plan build (whole grid: %d passes + launch events of 8 more; then the shares of a middle and of the last rank under the split, twice)" % passes)
         return self.split_times
 
     def south_cut(self, sc_y0=None):

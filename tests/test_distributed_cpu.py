@@ -173,9 +173,9 @@ def _calib_worker(rank, world, port, q):
         plan = _plan(sg_mod, 2)
         if rank == 0:
             # no GPU here: rank 0's measurement is replaced by fixed numbers; the broadcast and what follows are the real code
-            vals = [(7.25, 123.5)]
-            dist.broadcast_object_list(vals, src=0)
-            plan.set_split_times(vals[0][0], vals[0][1], "test")
+            t = torch.tensor([7.25, 123.5], dtype=torch.float64)
+            dist.broadcast(t, src=0)
+            plan.set_split_times(float(t[0]), float(t[1]), "test")
         else:
             plan.calibrate_split("cpu", rank=rank, world=world)
         q.put((rank, plan.split_times["tail_us"], plan.split_times["pass_us"],

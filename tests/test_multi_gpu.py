@@ -97,6 +97,8 @@ def test_checksum_is_independent_of_the_pipeline():
     assert p.returncode == 0, p.stderr[-3000:]
     c = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert c["field_checksums"] == a["field_checksums"] and c["world_size"] == 1 and c["per_rank"][0]["rank"] == 0
+    # ... and the split calibration ran its measurement and its broadcast over RCCL (a device tensor) at world size 1
+    assert c["band_split"] and "measured by rank 0" in c["band_split"]["source"] and 0 < c["band_split"]["tail_us"] < c["band_split"]["pass_us"]
 
 
 def test_host_pointer_layer_follows_the_current_device():
