@@ -255,48 +255,57 @@ class SupergridPlan(object):
 
     split_times = None
 
-    def set_split_times(self, tail_us, pass_us, source):
-        """The two numbers the band split takes the last rank's share from (rows_of): `tail_us`, what the bipolar quadrature's fix-up
+    def set_split_times(self, tail_us, pass_us, source, top_capacity=None):
+        """What the band split takes the last rank's share from (rows_of).  The MODEL: `tail_us`, what the bipolar quadrature's fix-up
         launch -- which only the rank with the top rows runs -- adds to that rank's pass, and `pass_us`, one pass of the whole grid on
-        one GPU.  The same values on every rank give the same edges on every rank."""
+        one GPU: share of the last rank = 1 - world * tail_us / pass_us of the others'.  A MEASURED share (`top_capacity`, from
+        calibrate_split) takes precedence for the world size it was measured at.  The same values on every rank give the same edges."""
         for s in self.subs:
-            s.tail_us, s.pass_us = float(tail_us), float(pass_us)
+            s.tail_us, s.pass_us, s.top_capacity = float(tail_us), float(pass_us), top_capacity
         self.split_times = {"tail_us": float(tail_us), "pass_us": float(pass_us), "source": source}
+        if top_capacity is not None:
+            self.split_times["top_capacity"] = {"world": int(top_capacity[0]), "share_of_last_rank": float(top_capacity[1])}
 
-    def calibrate_split(self, device, rank=0, world=1, passes=40, broadcast=True, force=False):
-        """Replace the fitted split constants by a measurement on THIS box, before any band buffer exists (rank 0 alone works, a few
-        hundred passes; the others wait in the broadcast): rank 0 runs the whole grid
-        as one rank (`passes` timed passes after 100 warm ones: pass_us; eight more with the library's launch events: the fix-up launch
-        less the cost of an event record, a first guess of tail_us; then, twice, the shares of a middle rank and of the last rank under the
-        current split, from which the tail follows as T_last - cap * T_middle and pass_us as world * T_middle) and broadcasts the two numbers; every rank then derives the same edges from them.  Needs a GPU on rank 0 and, for
-        world > 1 with ``broadcast``, an initialised process group.  Returns ``split_times`` (None when the split has no such term:
-        one rank, no bipolar cap, --skip_metrics).  OGG_TOP_RANK_TAIL_US in the environment still overrides the tail time.  ``force``: measure
-        and broadcast at world size 1 too (bench.py under OGG_FORCE_DIST=1: the RCCL broadcast on a one-GPU box)."""
+    def calibrate_split(self, device, rank=0, world=1, passes=40, broadcast=True, force=False, rounds=5):
+        """Replace the fitted split constants by a measurement on THIS box, before any band buffer exists (rank 0 alone works, about a
+        thousand passes; the others wait in the broadcast).  Rank 0 (i) runs the whole grid as one rank -- `passes` timed passes after
+        100 warm ones: pass_us; eight more with the library's launch events: the fix-up launch less the cost of an event record, a first
+        guess of tail_us and hence of the last rank's share c = 1 - world * tail_us / pass_us --, then (ii) up to `rounds` times (until the two agree to 1 %): times the share
+        of a middle rank and of the last rank under the current split (on its one GPU, one after the other) and scales
+        c <- c * T_middle / T_last, which equalises the two whatever makes the last rank slower (a fixed extra launch, or rows that cost
+        more than the row weights say on this box), and (iii) broadcasts (tail_us, pass_us, c).  Every rank then derives the same edges.
+        Needs a GPU on rank 0 and, for world > 1 with ``broadcast``, an initialised process group.  Returns ``split_times`` (None when
+        the split has no such term: one rank, no bipolar cap, --skip_metrics).  OGG_TOP_RANK_TAIL_US in the environment pins the
+        model's tail time and skips (ii).  ``force``: measure and broadcast at world size 1 too (bench.py under OGG_FORCE_DIST=1: the
+        RCCL broadcast on a one-GPU box)."""
         import os
         import time
         if (world <= 1 and not force) or self.split_times is None:
             return self.split_times
-        vals = [None]
+        vals = (0.0, 0.0, 0.0)
         if rank == 0:
             import torch
+
+            def timed_us(g, warm, n):
+                for _ in range(warm):
+                    g.run_pass()
+                torch.cuda.synchronize(g.device)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    g.run_pass()
+                torch.cuda.synchronize(g.device)
+                return (time.perf_counter() - t0) / n * 1e6
+
             g = Supergrid(self, rank=0, world=1, device=device, halo="recompute")
             g.launch, g.overlap = "pass", False
-            for _ in range(100):      # the clocks of a fresh process take ~30 ms to ramp
-                g.run_pass()
-            torch.cuda.synchronize(g.device)
-            t0 = time.perf_counter()
-            for _ in range(passes):
-                g.run_pass()
-            torch.cuda.synchronize(g.device)
-            pass_us = (time.perf_counter() - t0) / passes * 1e6
+            pass_us = timed_us(g, 100, passes)          # (the clocks of a fresh process take ~30 ms to ramp)
             g.reserve_pass_events(8)
             g.pass_events = []
             for _ in range(8):
                 g.run_pass()
             tail_us = g.pass_launch_times_ms()["pass_tail"]["ms"] * 1e3
             g.pass_events = None
-            # an interval between two event records holds the records' own cost besides the launch: two records back to back
-            # measure it (~3 us), and what is left is what the fix-up launch adds to a pass
+            # an interval between two event records holds the records' own cost besides the launch: two records back to back measure it
             st = g._stream()
             ev = g._new_events()
             gap = []
@@ -309,47 +318,39 @@ class SupergridPlan(object):
                 gap.append(ms.value * 1e3)
             for k in range(5):
                 L.call("ogg_event_destroy", ev[k])
-            tail_us = max(tail_us - min(gap), 1.0)
-            # ... which is a first guess only: what the last rank pays for its extra launch is the kernel AND the launch's own latency
-            # behind launch B.  Two refinements with the split itself: time the share of a middle rank and of the last rank under the
-            # current split (on this one GPU, one after the other) and take the tail from T_last = cap * T_middle + tail.
-            def share_us(r):
-                h = Supergrid(self, rank=r, world=world, device=device, halo="recompute")
-                h.launch, h.overlap = "pass", False
-                for _ in range(60):
-                    h.run_pass()
-                torch.cuda.synchronize(h.device)
-                t1 = time.perf_counter()
-                for _ in range(150):
-                    h.run_pass()
-                torch.cuda.synchronize(h.device)
-                dt = (time.perf_counter() - t1) / 150 * 1e6
-                h.close()
-                return dt
-
-            first_guess = tail_us
-            if not os.environ.get("OGG_TOP_RANK_TAIL_US"):
-                for _ in range(2):
-                    self.set_split_times(tail_us, pass_us, "calibrating")
-                    t_mid, t_top = share_us((world - 1) // 2), share_us(world - 1)
-                    cap = 1.0 - world * tail_us / pass_us if world * tail_us / pass_us <= 0.5 else 1.0
-                    tail_us = min(max(t_top - cap * t_mid, 0.5 * first_guess), 4.0 * first_guess)
-                    pass_us = world * t_mid
             g.close()
             del g
-            torch.cuda.empty_cache()
+            tail_us = max(tail_us - min(gap), 1.0)
+            cap = 0.0                                    # 0: no measured share (the model stands)
             if os.environ.get("OGG_TOP_RANK_TAIL_US"):
                 tail_us = float(os.environ["OGG_TOP_RANK_TAIL_US"])
-            vals = [(tail_us, pass_us)]
-        if broadcast:   # two doubles from rank 0: a device tensor over RCCL, through the host where the group is gloo (as all_reduce does)
+            elif world > 1:
+                cap = 1.0 - world * tail_us / pass_us if world * tail_us / pass_us <= 0.5 else 1.0
+                for _ in range(rounds):
+                    self.set_split_times(tail_us, pass_us, "calibrating", top_capacity=(world, cap))
+                    t = []
+                    for r in ((world - 1) // 2, world - 1):
+                        h = Supergrid(self, rank=r, world=world, device=device, halo="recompute")
+                        h.launch, h.overlap = "pass", False
+                        t.append(timed_us(h, 60, 150))
+                        h.close()
+                        del h
+                    cap = min(max(cap * t[0] / t[1], 0.3), 1.3)
+                    if abs(t[0] / t[1] - 1.0) < 0.01:      # the two shares within 1 %: balanced as far as a timing can tell
+                        break
+            torch.cuda.empty_cache()
+            vals = (tail_us, pass_us, cap)
+        if broadcast:   # three doubles from rank 0: a device tensor over RCCL, through the host where the group is gloo (as all_reduce does)
             import torch
             import torch.distributed as dist
             on_gpu = dist.get_backend() != "gloo"
-            t = torch.tensor(list(vals[0]) if rank == 0 else [0.0, 0.0], dtype=torch.float64, device=(device if on_gpu else "cpu"))
+            t = torch.tensor(list(vals), dtype=torch.float64, device=(device if on_gpu else "cpu"))
             dist.broadcast(t, src=0)
-            vals = [tuple(float(v) for v in t.tolist())]
-        tail_us, pass_us = vals[0]
-        self.set_split_times(tail_us, pass_us, "measured by rank 0 at plan build (whole grid: %d passes + launch events of 8 more; then the shares of a middle and of the last rank under the split, twice)" % passes)
+            vals = tuple(float(v) for v in t.tolist())
+        tail_us, pass_us, cap = vals
+        self.set_split_times(tail_us, pass_us, "measured by rank 0 at plan build (whole grid: %d passes + launch events of 8 more; then the shares "
+                             "of a middle and of the last rank under the split, until they agree to 1 %% or %d times)" % (passes, rounds),
+                             top_capacity=((world, cap) if cap > 0.0 else None))
         return self.split_times
 
     def south_cut(self, sc_y0=None):
@@ -474,10 +475,13 @@ class Supergrid(object):
         SupergridPlan when the grid has a bipolar cap with metrics)."""
         cost = getattr(s, "row_cost", None)
         tail_us, pass_us = getattr(s, "tail_us", 0.0), getattr(s, "pass_us", 0.0)
+        measured = getattr(s, "top_capacity", None)
         cap = 1.0
+        if world > 1 and measured is not None and int(measured[0]) == world:
+            cap = float(measured[1])        # the last rank's share as calibrate_split measured it for this world size
         # (a grid so small, or ranks so many, that the fix-up launch is more than half of a rank's share: the linear correction no longer
         # describes anything -- equal shares then, rather than a last rank clamped to a sliver or to no rows at all)
-        if world > 1 and tail_us > 0.0 and pass_us > 0.0 and world * tail_us / pass_us <= 0.5:
+        elif world > 1 and tail_us > 0.0 and pass_us > 0.0 and world * tail_us / pass_us <= 0.5:
             cap = min(1.0, 1.0 - world * tail_us / pass_us)
         if cost is None and cap == 1.0:
             return band(s.nj1, rank, world)

@@ -31,6 +31,10 @@ Three groups ("next round" item 1):
                     symmetry meridian, every row; and the pole row, every column.  Inputs: lamg, phig, lon_bp, rp as
                     generate_bipolar_cap_mesh (OGG:103-122) forms them in fp64.
 
+  bq   OGG:125-188  bipolar_cap_metrics_quad_fast(5) over bipolar_projection(metrics_only) (OGG:33-100) on the 1/8 degree cap: 14 cell
+                    rows (the joint, mid-cap, the ten rows under the pole incl. the j = ny - 0.001 row) x every 37th column and the ten
+                    columns around each symmetry meridian (the cells that touch the two pole points).
+
 Stored per value: hi = fp64(truth), lo = fp64(truth - hi)  (so that v - truth = (v - hi) - lo to 1e-32 relative), and
 the oracle's distance from the truth as measured when the fixture was made (`*_eref`), which the tests use as the unit
 of their tolerances.
@@ -318,6 +322,106 @@ def bp_group(pool, quick):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# bq: OGG:125-188 (bipolar_cap_metrics_quad_fast, order 5) over OGG:33-100 (metrics_only) in exact arithmetic
+# ---------------------------------------------------------------------------------------------------------------
+def bq_metrics(lamg, phig, lon_bp, rp):
+    """h_i_inv, h_j_inv of bipolar_projection(metrics_only=True) at one point.  OGG:41-47, 66-95."""
+    phig = 90 - 2 * mp.atan(mp.tan(M(0.5) * (90 - phig) * PI180) / rp) / PI180        # OGG:41
+    tmp = mdist_exact(lamg, lon_bp) * PI180
+    sinla = mp.sin(tmp)
+    sphig = mp.sin(phig * PI180)
+    alpha2 = mp.cos(tmp) ** 2
+    t = phig * PI180
+    huge = (mp.cos(t) == 0) or (mp.tan(t) ** 2 > HUGE)
+    A = sinla * sphig
+    chic = mp.acos(A)
+    tc = mp.tan(chic / 2)
+    phis = 90 - 2 * mp.atan(rp * tc) / PI180
+    M_inv = rp * (1 + tc ** 2) * (1 / (1 + (rp * tc) ** 2))                            # OGG:72-73
+    chig = (90 - phig) * PI180
+    tg = mp.tan(chig / 2)
+    N = rp * (1 + tg ** 2) * (1 / (1 + (rp * tg) ** 2))                                # OGG:76-77
+    N_inv = 1 / N
+    cos2phis = mp.cos(phis * PI180) ** 2
+    if huge:                                                                           # OGG:86, 94
+        hj2, hi2 = M_inv * M_inv, M_inv * M_inv
+    else:
+        b2 = mp.tan(t) ** 2
+        rden = 1 / (1 + alpha2 * b2)
+        hj2 = cos2phis * alpha2 * (1 - alpha2) * b2 * (1 + b2) * rden ** 2 + M_inv * M_inv * (1 - alpha2) * rden
+        hi2 = cos2phis * (1 + b2) * rden ** 2 + M_inv * M_inv * alpha2 * b2 * rden
+    return mp.sqrt(hi2), mp.sqrt(hj2) * N_inv
+
+
+def bq_cell(args):
+    (nx, ny, lat0, lon_bp, rp), j, i, jn, inn = args
+    lat0m, lonm, rpm = M(lat0), M(lon_bp), M(rp)
+    hi = [[None] * 5 for _ in range(5)]
+    hj = [[None] * 5 for _ in range(5)]
+    for a in range(5):
+        latg = lat0m + M(jn[a]) * (90 - lat0m) / ny                                    # OGG:127
+        for b in range(5):
+            long = lonm + M(inn[b]) * 360 / nx                                         # OGG:126
+            x, y = bq_metrics(long, latg, lonm, rpm)
+            hi[a][b] = x * 2 * M(np.pi) / nx                                           # OGG:131-132
+            hj[a][b] = y * (90 - lat0m) * PI180 / ny
+    w = [9, 49, 64, 49, 9]
+    d = M(1.0) / 180
+    area = d * d * sum(w[a] * w[b] * hi[a][b] * hj[a][b] for a in range(5) for b in range(5))
+    dx = d * (64 * hi[0][2] + 49 * (hi[0][1] + hi[0][3]) + 9 * (hi[0][0] + hi[0][4]))   # OGG:219-220
+    dy = d * (64 * hj[2][0] + 49 * (hj[1][0] + hj[3][0]) + 9 * (hj[0][0] + hj[4][0]))
+    return j, i, [split(dx * RE), split(dy * RE), split(area * RE * RE)]
+
+
+def bq_group(pool, quick):
+    out = {}
+    for Ni, Nj, lat0 in ((5760, 960, 64.03160594077568),):
+        lon_bp = -300.0
+        rp = float(np.tan(0.5 * (90 - lat0) * orc.PI_180))
+        rows = [0, 1, 2, 240, 480, 720, 900, 940, 950, 955, 956, 957, 958, 959]
+        cols = sorted(set(list(range(0, Ni, 37)) + [c for m in (Ni // 4, 3 * Ni // 4) for c in range(m - 5, m + 5)] + [Ni // 2 - 1, Ni // 2, Ni - 1]))
+        if quick:
+            rows, cols = rows[::5] + [959], cols[::20] + [Ni // 4 - 1, Ni // 4]
+        nodes = orc._lattice_1d(Nj, 5).reshape(Nj + 1, 5)
+        nodes[:, -1] = np.where(nodes[:, -1] == Nj, Nj - 0.001, nodes[:, -1])           # OGG:146-147
+        i1d = orc._lattice_1d(Ni, 5).reshape(Ni + 1, 5)
+        par = (Ni, Nj, lat0, lon_bp, rp)
+        jobs = [(par, j, i, nodes[j], i1d[i]) for j in rows for i in cols]
+        t0 = time.time()
+        res = pool.map(bq_cell, jobs, chunksize=8)
+        print("bq %d: %d cells in %.0f s" % (Ni, len(jobs), time.time() - t0), flush=True)
+        tag = "bq%d_" % Ni
+        jj = np.array([r[0] for r in res])
+        ii = np.array([r[1] for r in res])
+        vals = np.array([r[2] for r in res])
+        out.update({tag + "params": np.array([Ni, Nj, lat0, lon_bp, rp]), tag + "j": jj, tag + "i": ii})
+        o = [np.zeros(jj.size) for _ in range(3)]
+        for j in sorted(set(jj.tolist())):
+            r = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, lon_bp, rp, j_first=j, j_last=j + 1)
+            m = jj == j
+            for k in range(3):
+                o[k][m] = r[k][j, ii[m]]
+        for k, f in enumerate(("dx", "dy", "area")):
+            t = vals[:, k, :]
+            out[tag + f] = t.copy()
+            err = np.abs((o[k] - t[:, 0]) - t[:, 1])
+            # dy on the fold lines i = 0 and i = Ni/2 is 0 up to rounding (1 - cos^2 of 0 or pi: exactly 0 at i = 0, 1e-9 m at Ni/2): such
+            # values are compared absolutely (they are 1e-12 of the field), the relative figures are over the rest
+            nz = np.abs(t[:, 0]) > 1e-6 * np.abs(t[:, 0]).max()
+            assert np.all(np.abs(o[k][~nz]) < 1e-6) and err[~nz].max(initial=0.0) < 1e-6
+            pole = (jj == Nj - 1) & np.isin(ii, (Ni // 4 - 1, Ni // 4, 3 * Ni // 4 - 1, 3 * Ni // 4))   # the four cells that touch a pole point
+            # cells within 6 columns of a symmetry meridian (acos(A) at A -> 1 towards the pole points) or next to the fold lines
+            # i = 0, Ni/2 (1 - cos^2 of an angle next to 0 or pi: cancellation in the reference's own formula, OGG:82-84)
+            edge = ((np.abs(ii - Ni // 4) <= 6) | (np.abs(ii - 3 * Ni // 4) <= 6) | (np.abs(ii - Ni // 2) <= 1) | (ii <= 1) | (ii >= Ni - 2)) & ~pole
+            out[tag + "pole_cells"], out[tag + "edge_cells"] = pole, edge
+            for nm, m in (("", nz & ~pole & ~edge), ("_edgecells", nz & edge), ("_polecells", nz & pole)):
+                out[tag + f + "_eref_rel" + nm] = np.array((err[m] / np.abs(t[m, 0])).max())
+                out[tag + f + "_eref_abs" + nm] = np.array(err[m].max())
+                print("bq %d oracle vs truth %s%s: rel %.3e abs %.3e" % (Ni, f, nm, (err[m] / np.abs(t[m, 0])).max(), err[m].max()))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=8)
@@ -327,6 +431,7 @@ def main():
     out = {"dps": np.array(mp.mp.dps)}
     with Pool(a.procs) as pool:
         out.update(md_group(pool, a.quick))
+        out.update(bq_group(pool, a.quick))
         out.update(bp_group(pool, a.quick))
         out.update(dp_group(pool, a.quick))
     path = a.out if not a.quick else "/tmp/truth_table_quick.npz"

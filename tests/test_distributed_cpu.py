@@ -173,9 +173,9 @@ def _calib_worker(rank, world, port, q):
         plan = _plan(sg_mod, 2)
         if rank == 0:
             # no GPU here: rank 0's measurement is replaced by fixed numbers; the broadcast and what follows are the real code
-            t = torch.tensor([7.25, 123.5], dtype=torch.float64)
+            t = torch.tensor([7.25, 123.5, 0.875], dtype=torch.float64)
             dist.broadcast(t, src=0)
-            plan.set_split_times(float(t[0]), float(t[1]), "test")
+            plan.set_split_times(float(t[0]), float(t[1]), "test", top_capacity=(world, float(t[2])))
         else:
             plan.calibrate_split("cpu", rank=rank, world=world)
         q.put((rank, plan.split_times["tail_us"], plan.split_times["pass_us"],
@@ -197,3 +197,11 @@ def test_calibrated_split_is_broadcast_from_rank_0():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert res[0][1:] == res[1][1:] and res[0][1] == 7.25 and res[0][2] == 123.5
+    # the measured share took precedence over the model's 1 - 2 * 7.25 / 123.5: the last rank of two holds 0.875 / 1.875 of the Mercator rows
+    import ocean_model_grid_generator_amd.supergrid as sg_mod
+    plan = _plan(sg_mod, 2)
+    plan.set_split_times(7.25, 123.5, "test", top_capacity=(2, 0.875))
+    merc = next(s for s in plan.subs if s.name == "Merc")
+    lo, hi = sg_mod.Supergrid.rows_of(merc, 1, 2)
+    assert abs((hi - lo) / merc.nj1 - 0.875 / 1.875) < 2.0 / merc.nj1
+    assert sg_mod.Supergrid.rows_of(merc, 2, 3) != sg_mod.Supergrid.rows_of(merc, 1, 2)    # another world size: the model again

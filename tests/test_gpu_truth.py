@@ -174,3 +174,54 @@ def test_bipolar_projection_vs_truth(ogg, truth, Ni):
             floor = 1e-13         # where the reference is exact (the pole row's x is 0 / 180 / 360 by the guard) allow the coordinates' noise floor
             assert r["hip_projection_vs_truth_deg"] <= K_REF * max(eref, floor), (nm, f, r, eref)
             assert r["hip_mesh_kernel_vs_truth_deg"] <= K_REF * max(eref, floor), (nm, f, r, eref)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# OGG:125-188 over OGG:33-100: bipolar cap quadrature (order 5), 1/8 degree cap
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("guard_k", [None, "0"])
+def test_bipolar_quadrature_vs_truth(ogg, truth, monkeypatch, guard_k):
+    """The bipolar quadrature -- the algebraic per-point metric with its exactness guard and literal fix-up (default), and with EVERY cell
+    literal (OGG_BP_GUARD_K=0) -- against the exact value of the reference's formula on 14 cell rows of the 1/8 degree cap, the four cells
+    that touch a pole point included.  Those four are where the reference is worst conditioned (acos(A) at A -> 1 behind the j = ny - 0.001
+    node of OGG:146-147): its own fp64 area is ~8e-9 relative (0.04 m^2) away from the exact value there; next to the symmetry meridians and to
+    the fold lines i = 0, Ni/2 (1 - cos^2 of an angle next to 0 or pi, OGG:82-84) 1e-11; elsewhere 1e-13 and below."""
+    if guard_k is not None:
+        monkeypatch.setenv("OGG_BP_GUARD_K", guard_k)
+    tag = "bq5760_"
+    Ni, Nj, lat0, lon_bp, rp = truth[tag + "params"]
+    Ni, Nj = int(Ni), int(Nj)
+    jj, ii = truth[tag + "j"], truth[tag + "i"]
+    got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, float(lat0), float(lon_bp), float(rp))
+    o = [np.zeros(jj.size) for _ in range(3)]
+    for j in sorted(set(jj.tolist())):
+        r = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, float(lat0), float(lon_bp), float(rp), j_first=j, j_last=j + 1)
+        m = jj == j
+        for k in range(3):
+            o[k][m] = r[k][j, ii[m]]
+    pole, edge = truth[tag + "pole_cells"], truth[tag + "edge_cells"]
+    groups = (("regular_cells", ~pole & ~edge, ""), ("cells_next_to_a_symmetry_meridian_or_fold_line", edge, "_edgecells"),
+              ("the_four_cells_that_touch_a_pole_point", pole, "_polecells"))
+    rep = {}
+    for k, f in enumerate(("dx", "dy", "area")):
+        t = truth[tag + f]
+        vh = got[k][jj, ii]
+        nz = np.abs(t[:, 0]) > 1e-6 * np.abs(t[:, 0]).max()
+        assert np.all(np.abs(vh[~nz]) < 1e-6)               # dy on the fold lines i = 0, Ni/2: 0 up to rounding (< 1e-6 m), like the reference's
+        for nm, g, _ in groups:
+            m = nz & g
+            rep["%s/%s" % (nm, f)] = {"oracle_vs_truth": stats(err(o[k][m], t[m]), t[m, 0]), "hip_vs_truth": stats(err(vh[m], t[m]), t[m, 0]),
+                                      "hip_vs_oracle": stats(np.abs(vh[m] - o[k][m]), o[k][m]), "n": int(m.sum())}
+    REPORT["bipolar_quadrature_OGG125_188/Ni%d%s" % (Ni, "" if guard_k is None else "_every_cell_literal")] = rep
+    _save()
+    for f in ("dx", "dy", "area"):
+        for nm, _, sfx in groups:
+            eref = float(truth[tag + f + "_eref_rel" + sfx])
+            r = rep["%s/%s" % (nm, f)]
+            assert r["oracle_vs_truth"]["max_rel"] <= 2.0 * eref + 1e-16, (f, nm, r, eref)
+            assert r["hip_vs_truth"]["max_rel"] <= K_REF * max(eref, 2e-14), (f, nm, r, eref)
+    # north_star's 1e-6 m^2: against the ORACLE the cap's area is within 7.2e-8 m^2 (tests/test_gpu_parity.py); against the truth the
+    # reference itself is 2.3e-6 m^2 away in regular cells (5e-13 of a 4.8e6 m^2 cell) and 0.04 m^2 in the four pole cells, and so is the kernel
+    assert rep["regular_cells/area"]["hip_vs_truth"]["max_abs"] <= K_REF * float(truth[tag + "area_eref_abs"])
+    assert rep["regular_cells/area"]["hip_vs_oracle"]["max_abs"] < 1e-6
+    assert float(truth[tag + "area_eref_abs_polecells"]) > 1e-3
