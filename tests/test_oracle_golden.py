@@ -195,3 +195,27 @@ def test_truth_table_displaced_pole_rows():
     # the fp64 reference is ~1e-9 (relative) away from the exact value of its own finite-difference quadrature at 1/8 degree
     for f in ("dx", "dy", "area"):
         assert 5e-10 < float(T["dp_A_%s_eref" % f]) < 3e-9
+
+
+def test_truth_table_bipolar_quadrature_rows():
+    """OGG:125-188: the oracle's distance from the exact value of the reference's quadrature, by kind of cell -- 5e-13 (area, regular
+    cells: 2.3e-6 m^2, i.e. north_star's 1e-6 m^2 is below the reference's own rounding error here too), 1e-11 next to the symmetry
+    meridians and the fold lines, 8e-9 (0.04 m^2) in the four cells that touch a pole point."""
+    T = np.load(os.path.join(GOLD, "truth_table.npz"))
+    tag = "bq5760_"
+    Ni, Nj, lat0, lon_bp, rp = T[tag + "params"]
+    Ni, Nj = int(Ni), int(Nj)
+    jj, ii, pole, edge = T[tag + "j"], T[tag + "i"], T[tag + "pole_cells"], T[tag + "edge_cells"]
+    assert pole.sum() == 4 and edge.sum() > 100 and (~pole & ~edge).sum() > 2000
+    for j in (0, 480, 957, 959):
+        o = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, float(lat0), float(lon_bp), float(rp), j_first=j, j_last=j + 1)
+        m = jj == j
+        for k, f in enumerate(("dx", "dy", "area")):
+            t = T[tag + f][m]
+            nz = np.abs(t[:, 0]) > 1e-6 * np.abs(T[tag + f][:, 0]).max()
+            e = _err(o[k][j, ii[m]], t)
+            for sfx, g in (("", ~pole[m] & ~edge[m]), ("_edgecells", edge[m]), ("_polecells", pole[m])):
+                sel = nz & g
+                if sel.any():
+                    assert (e[sel] / np.abs(t[sel, 0])).max() <= 2.0 * float(T[tag + f + "_eref_rel" + sfx]) + 1e-16, (j, f, sfx)
+    assert 1e-6 < float(T[tag + "area_eref_abs"]) < 1e-5 and 1e-3 < float(T[tag + "area_eref_abs_polecells"]) < 1.0
