@@ -258,11 +258,13 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
  * the reference (OGG:583-584), so only orders 2 and 4 are valid.  Band form as for the bipolar cap; cell rows
  * below j0 are simply not evaluated (main() discards the doughnut rows, OGG:1177-1186).
  * arc_form selects how the great-arc distance between two probes of the finite-difference stencil is taken:
+ *   OGG_DP_ARC_CHORD    the finite-difference stencil of the reference, distance of two probes from their positions on the sphere (no
+ *                       atan2, no unwrap): ~6x less arithmetic than the literal form, and closer to what the reference's formula means
+ *                       (below).  Since round 4 THE default: what the entry points without an arc_form argument run, and what the
+ *                       Python host (main(), displacedPoleCap_metrics_quad, SupergridPlan, bench.py) asks for unless OGG_DP_ARC /
+ *                       dp_arc / arc_form says literal;
  *   OGG_DP_ARC_LITERAL  the reference's operation sequence (haversine of the projected, unwrapped longitudes and latitudes,
- *                       OGG:522-532); what the entry points WITHOUT an arc_form argument run;
- *   OGG_DP_ARC_CHORD    same stencil, distance from the probes' positions on the sphere (no atan2 / unwrap): ~6x less arithmetic.
- *                       Not the reference's operation sequence -- and closer to what its formula means (below).  Since round 4 the
- *                       default of the Python host (main(), displacedPoleCap_metrics_quad, SupergridPlan, bench.py; OGG_DP_ARC).
+ *                       OGG:522-532): opt-in through the *_form entry points and the band descriptor of the pass.
  * Measured on the 5760 x 560 cap of BASELINE config 4 (1/8 degree), max relative difference of dx / dy / area
  *   from the numpy oracle (profiles/dp_parity.json):             literal 1.3e-9 / 1.2e-9 / 7.6e-10   chord 1.5e-9 / 1.3e-9 / 9.8e-10
  *   from a 50-digit evaluation of the reference's own formula on 10 500 cells (tests/golden/truth_table.npz, tests/test_gpu_truth.py,
@@ -358,11 +360,9 @@ int ogg_bswap64_dev(long n, const void* src, void* dst, void* stream);
 /* Self-test of the device-library functions the kernels restate with their coefficients as scalar operands (ogg_math.h,
  * ogg_bipolar_dev.h): which = 0: asin on [0, 1] (x); 1: atan (x, any); 2: atan2(y, x), finite; 3: 1.0 / x and 4: sqrt(x) without
  * scaling and special cases, 2^-700 <= x <= 2^700; 5: y / x without scaling, 2^-300 <= |x|, |y| <= 2^300 or y = +-0; 6: atan (x) and
- * 7: atan2(y, x) with their coefficients in vector registers (the literal displaced-pole quadrature's forms); 8: atan2(y, x) with its
- * quotient taken without scaling (finite arguments, the larger one within 2^-300 .. 2^300); 9: atan2(y, x) for ANY arguments, infinities
- * and NaNs included (the generic stencil kernel's form; two NaNs count as equal); 10: cos (x), 11 / 12: the sine / cosine of sincos (x)
- * with their constants as scalar operands (any x; 2^30 and above, infinities and NaNs go to the library); 13 / 14: mdist(x, y) (OGG:682-684) from
- * one reduction (the generic stencil kernel's form) / from two, against numpy.mod's own fmod form.  The number of k < n for which the
+ * 7: atan2(y, x) with their coefficients in vector registers (the literal displaced-pole quadrature's forms); 9: atan2(y, x) for ANY
+ * arguments, infinities and NaNs included (the generic stencil kernel's form; two NaNs count as equal); 13 / 14: mdist(x, y) (OGG:682-684) from
+ * one reduction (the generic stencil kernel's form) / from two, against numpy.mod's own fmod form.  (8, 10, 11, 12 -- restatements that no kernel uses any more -- were removed with them in round 4: OGG_EARG.)  The number of k < n for which the
  * restatement differs IN ANY BIT from the library's own function is ADDED to *n_diff (device memory, 8 bytes, zeroed by the caller). */
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream);
 /* The five sums behind metrics_error (OGG:732-770) of one sub-grid band, on the device and deterministic:

@@ -433,7 +433,7 @@ int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long 
 
 int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp, double Re,
                                     double* dxq, double* dyq, double* daq) {
-    return ogg_displaced_pole_metrics_quad_form(OGG_DP_ARC_LITERAL, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, dxq, dyq, daq);
+    return ogg_displaced_pole_metrics_quad_form(OGG_DP_ARC_CHORD, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, dxq, dyq, daq);
 }
 
 // ---- small element-wise entry points -----------------------------------------------------------------------

@@ -10,7 +10,7 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool diff = false;
     if (k < n) {
-        double a, b;
+        double a = 0.0, b = 0.0;
         if (which == 0)
             a = asin_unit(x[k]), b = asin(x[k]);
         else if (which == 1)
@@ -31,9 +31,6 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
             else
                 a = atan2_lib(y[k], x[k], c), b = atan2(y[k], x[k]);
             c.keep();
-        } else if (which == 8) {              // atan2 with the quotient taken without scaling, literal coefficients
-            const AtanLiterals c;
-            a = atan2_lib_normal(y[k], x[k], c), b = atan2(y[k], x[k]);
         } else if (which == 9) {              // atan2 for any arguments (infinities, NaNs)
             a = atan2_lib_any(y[k], x[k]), b = atan2(y[k], x[k]);
             if (a != a && b != b) b = a;      // any NaN is the same answer
@@ -43,20 +40,6 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
             m1 = (m1 < 0.0) ? m1 + 360.0 : m1, m2 = (m2 < 0.0) ? m2 + 360.0 : m2;
             m1 = (m1 == 0.0) ? 0.0 : m1, m2 = (m2 == 0.0) ? 0.0 : m2;
             b = fmin(m1, m2);
-            if (a != a && b != b) b = a;
-        } else {                              // which == 10: cos; 11 / 12: the sine / cosine of sincos -- restated with scalar constants
-            TrigCoefs t;
-            t.load(kTrigRed);
-            double s1, c1, s2, c2;
-            sincos_lib(x[k], t, s1, c1);
-            sincos(x[k], &s2, &c2);
-            if (which == 10)
-                a = cos_lib(x[k], t), b = cos(x[k]);
-            else if (which == 11)
-                a = s1, b = s2;
-            else
-                a = c1, b = c2;
-            t.keep();
             if (a != a && b != b) b = a;
         }
         diff = __double_as_longlong(a) != __double_as_longlong(b);
@@ -69,8 +52,8 @@ __global__ void libm_check_kernel(int which, long n, const double* __restrict__ 
 extern "C" {
 
 int ogg_libm_check_dev(int which, long n, const double* x, const double* y, unsigned long long* n_diff, void* stream) {
-    OGG_REQUIRE(which >= 0 && which <= 14 && n >= 0 && x && n_diff &&
-                    ((which != 2 && which != 5 && which != 7 && which != 8 && which != 9 && which != 13 && which != 14) || y), OGG_EARG,
+    OGG_REQUIRE(which >= 0 && which <= 14 && which != 8 && !(which >= 10 && which <= 12) && n >= 0 && x && n_diff &&
+                    ((which != 2 && which != 5 && which != 7 && which != 9 && which != 13 && which != 14) || y), OGG_EARG,
                 "ogg_libm_check: bad argument");
     if (n == 0) return OGG_OK;
     libm_check_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ogg::as_stream(stream)>>>(which, n, x, y, n_diff);

@@ -564,14 +564,14 @@ int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx
 int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
                                            double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
                                            double* daq, void* workspace, long workspace_bytes, void* stream) {
-    return ogg_displaced_pole_metrics_quad_form_ws_dev(OGG_DP_ARC_LITERAL, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows,
+    return ogg_displaced_pole_metrics_quad_form_ws_dev(OGG_DP_ARC_CHORD, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows,
                                                        n_cell_rows, dxq, dyq, daq, workspace, workspace_bytes, stream);
 }
 
 int ogg_displaced_pole_metrics_quad_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
                                         double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq,
                                         double* daq, void* stream) {
-    return ogg_displaced_pole_metrics_quad_form_ws_dev(OGG_DP_ARC_LITERAL, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows,
+    return ogg_displaced_pole_metrics_quad_form_ws_dev(OGG_DP_ARC_CHORD, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0, n_dx_rows,
                                                        n_cell_rows, dxq, dyq, daq, nullptr, 0, stream);
 }
 

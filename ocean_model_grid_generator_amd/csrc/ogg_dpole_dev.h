@@ -502,7 +502,7 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
 //     the chord form                       7.61e-10 / 2.74e-10 / 8.26e-10
 // i.e. the chord form is CLOSER to what the reference's formula means than the reference's own fp64 evaluation, at a sixth of the
 // arithmetic.  Since round 4 it is the default of main() and of the Python entry points (OGG_DP_ARC / dp_arc / arc_form = literal opts
-// back into the reference's operation sequence); the C entry points without an arc_form argument keep the literal form.
+// back into the reference's operation sequence) and of the C entry points without an arc_form argument.
 // A probe's point on the sphere in homogeneous form: with w = num / den the conformal image of the probe (OGG:454-455),
 // (X, Y) = r_joint w its gnomonic image and (X, Y, -1) a vector along the point, so is
 //   (P, Q, -D) = (r_joint Re(num conj(den)), r_joint Im(num conj(den)), -|den|^2)

@@ -44,21 +44,6 @@ OGG_DEV double pymod360(double a) {
     return (r == 0.0) ? 0.0 : r;
 }
 
-// The same value without a branch per lane (the off-by-one quotient is repaired by selects; a wave with an operand beyond 1e12 takes
-// pymod360, behind one ballot): for the streaming stencil kernel, whose four mod-360 per point were eight small divergent blocks.
-OGG_DEV double pymod360_sel(double a) {
-    if (__builtin_expect(__ballot(!(fabs(a) < 1.0e12)) != 0ull, 0)) return pymod360(a);
-    const double q = floor(a * (1.0 / 360.0));
-    const double r = fma(-q, 360.0, a);
-    const double qc = (r < 0.0) ? q - 1.0 : q + 1.0;
-    const double rc = fma(-qc, 360.0, a);
-    const double v = (r < 0.0 || (r >= 360.0 && rc >= 0.0)) ? rc : r;    // (r = 360.0 by rounding, rc < 0: see pymod360)
-    return (v == 0.0) ? 0.0 : v;
-}
-OGG_DEV double mdist_sel(double x1, double x2) {
-    return fmin(pymod360_sel(x1 - x2), pymod360_sel(x2 - x1));
-}
-
 // a / PI_180 for finite a, correctly rounded -- the same bits as the IEEE division a / kPi180 -- in 3 instructions instead
 // of the 11 of a full fp64 divide (division by a constant: q = a rc, then one residual correction; checked against the
 // divide instruction on 3e8 random operands over 40 binades).
@@ -153,21 +138,6 @@ OGG_DEV cplx cdiv(cplx a, cplx b) {
     return o;
 }
 
-// The same division for operands known to be normal (|b| within 2^+-300, a zero or normal; see div_ieee_normal), without a branch:
-// the two arms of Smith's algorithm differ only in which component plays which part, and a + b = b + a, so selects give the same bits.
-OGG_DEV cplx cdiv_normal(cplx a, cplx b) {
-    const bool re_big = fabs(b.re) >= fabs(b.im);
-    const double big = re_big ? b.re : b.im, small = re_big ? b.im : b.re;
-    const double p = re_big ? a.re : a.im, m = re_big ? a.im : a.re;   // o.re = (p + m rat) scl in both arms
-    const double rat = div_ieee_normal(small, big);
-    const double scl = rcp_ieee_normal(big + small * rat);
-    cplx o;
-    o.re = (p + m * rat) * scl;
-    const double d = m - p * rat;            // re_big: a.im - a.re rat;  else: -(a.im rat - a.re)
-    o.im = (re_big ? d : -d) * scl;
-    return o;
-}
-
 // numpy.absolute(complex128): max * sqrt(1 + (min/max)^2) with one fma.
 OGG_DEV double cabs_np(cplx w) {
     const double ar = fabs(w.re), ai = fabs(w.im);
@@ -176,14 +146,6 @@ OGG_DEV double cabs_np(cplx w) {
     const double r = b / a;
     return a * sqrt_ieee_normal(fma(r, r, 1.0));   // the argument lies in [1, 2]: IEEE sqrt, the same bits, without its scaling / special cases
 }
-// for a normal, non-zero larger component (no branch, no scaling in the division)
-OGG_DEV double cabs_np_normal(cplx w) {
-    const double ar = fabs(w.re), ai = fabs(w.im);
-    const double a = fmax(ar, ai), b = fmin(ar, ai);
-    const double r = div_ieee_normal(b, a);
-    return a * sqrt_ieee_normal(fma(r, r, 1.0));
-}
-
 // 1/x and 1/sqrt(x) for NORMAL, positive x from the hardware seed (v_rcp_f64 / v_rsq_f64, relative error e <= 2^-24 measured,
 // scripts/microbench/rcp_rsq_accuracy.hip) and ONE third-order step -- 1/x = y (1 + e + e^2 + ...), x^(-1/2) = y (1 + e/2 + 3 e^2/8 + ...)
 // with e = 1 - x y (resp. 1 - x y^2) exact from the fma -- which leaves e^3 = 2^-72 of truncation: 0.5 / 1.0 ulp at worst over 1.7e7
@@ -266,24 +228,6 @@ static __constant__ double kAtanRed[20] = {-0x1.5555555555523p-2, 0x1.9999999995
 
 typedef ScalarPoly<20> AtanCoefs;   // AtanCoefs c; c.load(kAtanRed); ... atan2_lib(y, x, c) ...; c.keep();
 
-// The same polynomial with its coefficients as literals in the code (the compiler materialises each with two s_mov_b32 or two v_mov_b32
-// in front of its fma, as it does for the library's own polynomials).
-struct AtanLiterals {
-    OGG_DEV double eval(double z) const {
-        constexpr double k[20] = {-0x1.5555555555523p-2, 0x1.99999999952ccp-3,  -0x1.2492492376b7dp-3, 0x1.c71c717e1913cp-4,
-                                  -0x1.745d119378e4fp-4, 0x1.3b13657b87036p-4,  -0x1.110e48b207f05p-4, 0x1.e1bb48427b883p-5,
-                                  -0x1.ae5ce6a214619p-5, 0x1.82d5d6ef28734p-5,  -0x1.59976e82d3ff0p-5, 0x1.2c15b5711927ap-5,
-                                  -0x1.e9ae6fc27006ap-6, 0x1.67e295f08b19fp-6,  -0x1.c6ea4a57d9582p-7, 0x1.d6d43a595c56fp-8,
-                                  -0x1.7952daf56de9bp-9, 0x1.b2bb069efb384p-11, -0x1.3e260bd3237f4p-13, 0x1.ba404b5e68a13p-17};
-        double p = k[19];
-#pragma unroll
-        for (int i = 18; i >= 0; --i) p = fma(p, z, k[i]);
-        return p;
-    }
-    OGG_DEV void load(const double*) {}
-    OGG_DEV void keep() const {}
-};
-
 // ... and with its coefficients resident in VECTOR registers (40 of them), for a kernel that has vector registers to spare but no scalar
 // ones (a wave limited to two per SIMD by its other state): load() once in front of the loop.  The fma is written as the three-address
 // VOP3 instruction -- left to itself the compiler takes the two-address v_fmac_f64 and copies the coefficient in front of every step
@@ -352,25 +296,6 @@ OGG_DEV double atan_lib_wave(double x, const C& c) {
     return copysign(atanred_lib(fabs(x), c), x);
 }
 
-// atan(x) for |x| <= 1 (the caller's guarantee: nothing to invert), the same bits as atan_lib / atan
-template <class C>
-OGG_DEV double atan_lib_le1(double x, const C& c) {
-    return copysign(atanred_lib(fabs(x), c), x);
-}
-
-// atan2 for finite arguments of which the larger is normal (|.| within 2^+-300) or both are zero: the quotient without scaling
-template <class C>
-OGG_DEV double atan2_lib_normal(double y, double x, const C& c) {
-    const double ay = fabs(y), ax = fabs(x);
-    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-    double a = atanred_lib(div_ieee_normal(mn, mx), c);     // 0 / 0: NaN, replaced below (y == 0)
-    const bool xneg = __double2hiint(x) < 0;
-    a = (ax < ay) ? 0x1.921fb54442d18p+0 - a : a;
-    a = xneg ? 0x1.921fb54442d18p+1 - a : a;
-    a = (y == 0.0) ? (xneg ? 0x1.921fb54442d18p+1 : 0.0) : a;
-    return copysign(a, y);
-}
-
 template <class C>
 OGG_DEV double atan2_lib(double y, double x, const C& c) {   // finite arguments
     const double ay = fabs(y), ax = fabs(x);
@@ -415,81 +340,6 @@ OGG_DEV double atan2_lib_any(double y, double x) {
     const double r = atan2_lib_any(y, x, c);
     c.keep();
     return r;
-}
-
-// sin and cos with the SAME bits as the device library's (ROCm 7.2 ocml: __ocml_cos_f64 / __ocml_sincos_f64 = the three-constant
-// Cody-Waite reduction __ocmlpriv_trigredsmall_f64 for |x| < 2^30 and the paired kernel __ocmlpriv_sincosred2_f64, read from the
-// library's bitcode), restated operation for operation with every constant a scalar operand: the library materialises its 11
-// polynomial coefficients and 5 reduction constants with two vector moves each, per call.  A wave with an argument of 2^30 or more (or
-// an infinity / NaN) takes the library's own function, behind one ballot.  Bit-identity is a test (ogg_libm_check_dev, which = 10..12).
-static __constant__ double kTrigRed[16] = {
-    0x1.45f306dc9c883p-1,                                               // [0] 2 / pi
-    0x1.921fb54442d18p+0, 0x1.1a62633145c00p-54, 0x1.b839a252049c0p-104,   // [1..3] pi / 2 in three pieces
-    // [4..9] cosine kernel, constant term first
-    0x1.5555555555555p-5, -0x1.6c16c16c16967p-10, 0x1.a01a019f4ec90p-16, -0x1.27e4fa17f65f6p-22, 0x1.1eeb69037ab78p-29, -0x1.907db46cc5e42p-37,
-    // [10..14] sine kernel, constant term first; [15] 1 / 6
-    0x1.1111111110bb3p-7, -0x1.a01a019e83e5cp-13, 0x1.71de3796cde01p-19, -0x1.ae600b42fdfa7p-26, 0x1.5e0b2f9a43bb8p-33, 0x1.5555555555555p-3};
-
-typedef ScalarPoly<16> TrigCoefs;   // TrigCoefs t; t.load(kTrigRed); ... sincos_lib(x, t, s, c) ...; t.keep();
-
-// sin |x| and cos |x| reduced to the first quadrant, and the quadrant (0..3); |x| < 2^30
-OGG_DEV void sincos_reduced(double ax, const TrigCoefs& t, double& sv, double& cv, int& quad) {
-    const double* k = t.k;
-    const double n = rint(ax * k[0]);
-    const double r4 = fma(n, -k[1], ax);
-    const double r5 = fma(n, -k[2], r4);
-    const double m6 = n * k[2];
-    const double e8 = fma(n, k[2], -m6);
-    const double d9 = r4 - m6;
-    const double d11 = (r4 - d9) - m6;
-    const double d14 = ((d9 - r5) + d11) - e8;
-    const double d15 = fma(n, -k[3], d14);
-    const double hi = r5 + d15;
-    const double lo = d15 - (hi - r5);
-    quad = (int)n & 3;
-    // the paired kernel
-    const double z = hi * hi;
-    const double hz = z * 0.5;
-    const double c5 = 1.0 - hz;
-    const double c7 = (1.0 - c5) - hz;
-    const double zz = z * z;
-    double pc = k[9];
-#pragma unroll
-    for (int i = 8; i >= 4; --i) pc = fma(z, pc, k[i]);
-    const double c15 = fma(hi, -lo, c7);
-    cv = c5 + fma(zz, pc, c15);
-    double ps = k[14];
-#pragma unroll
-    for (int i = 13; i >= 10; --i) ps = fma(z, ps, k[i]);
-    const double xz = hi * (-z);
-    const double s25 = fma(xz, ps, lo * 0.5);
-    const double s26 = fma(z, s25, -lo);
-    sv = hi - fma(xz, -k[15], s26);
-}
-
-OGG_DEV double cos_lib(double x, const TrigCoefs& t) {
-    const double ax = fabs(x);
-    if (__builtin_expect(__ballot(!(ax < 0x1p30)) != 0ull, 0)) return cos(x);
-    double sv, cv;
-    int q;
-    sincos_reduced(ax, t, sv, cv, q);
-    const double r = (q & 1) ? -sv : cv;
-    return (q > 1) ? -r : r;
-}
-
-OGG_DEV void sincos_lib(double x, const TrigCoefs& t, double& s, double& c) {
-    const double ax = fabs(x);
-    if (__builtin_expect(__ballot(!(ax < 0x1p30)) != 0ull, 0)) {
-        sincos(x, &s, &c);
-        return;
-    }
-    double sv, cv;
-    int q;
-    sincos_reduced(ax, t, sv, cv, q);
-    const double rs = (q & 1) ? cv : sv, rc = (q & 1) ? -sv : cv;
-    const double ss = (q > 1) ? -rs : rs;
-    s = (__double2hiint(x) < 0) ? -ss : ss;     // the argument's sign bit is XOR-ed in (also for x = -0)
-    c = (q > 1) ? -rc : rc;
 }
 
 // Neighbour lanes of a wave64 through DPP wave shifts (gfx9: wave_shr:1 = 0x138, wave_shl:1 = 0x130): two VALU moves per

@@ -506,13 +506,20 @@ struct PassPipe {
     int ready_slot = -1;                    // the slot whose tables the previous pass's launch B built
     unsigned long long carried_runs = 0;    // passes that started with launch B
     int device = 0;
+    hipStream_t last_stream = nullptr;      // the stream of the last pass (the plan's passes are ordered by the caller's stream)
+    bool ran = false;
 
     ~PassPipe() {
         if (n_slots > 1) {
             int current = 0;
             (void)hipGetDevice(&current);
             (void)hipSetDevice(device);
-            (void)hipDeviceSynchronize();   // nothing of the plan may still be in flight when its workspaces go
+            // nothing of the plan may still be in flight when its workspaces go: wait for the stream of its last pass only (not for the
+            // whole device: other streams are none of the plan's business); a stream that no longer exists: the device, to be safe
+            if (ran && hipStreamSynchronize(last_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
             for (auto& slot_ws : own_ws)
                 for (void* w : slot_ws)
                     if (w) (void)hipFree(w);
@@ -563,6 +570,7 @@ int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, doubl
 }
 
 int run_pass_pipe(PassPipe& H, void** events5, double* alg_bytes4, void* stream) {
+    H.last_stream = ogg::as_stream(stream), H.ran = true;
     if (H.n_slots == 1) return run_pass_plan_any(H.slot[0], events5, alg_bytes4, stream);
     // Under stream capture the launches become graph nodes that are REPLAYED: a replay must find nothing that a previous pass left behind, so
     // the captured pass runs its own launch A (which resets the slot's counters, tickets and look-back words) and builds nobody's next
