@@ -273,7 +273,7 @@ class SupergridPlan(object):
         guess of tail_us and hence of the last rank's share c = 1 - world * tail_us / pass_us --, then (ii) up to `rounds` times (until the two agree to 1 %): times the share
         of a middle rank and of the last rank under the current split (on its one GPU, one after the other) and scales
         c <- c * T_middle / T_last, which equalises the two whatever makes the last rank slower (a fixed extra launch, or rows that cost
-        more than the row weights say on this box), and (iii) broadcasts (tail_us, pass_us, c).  Every rank then derives the same edges.
+        more than the row weights say on this box); the share of the round whose slower rank was fastest is kept; and (iii) broadcasts (tail_us, pass_us, c).  Every rank then derives the same edges.
         Needs a GPU on rank 0 and, for world > 1 with ``broadcast``, an initialised process group.  Returns ``split_times`` (None when
         the split has no such term: one rank, no bipolar cap, --skip_metrics).  OGG_TOP_RANK_TAIL_US in the environment pins the
         model's tail time and skips (ii).  ``force``: measure and broadcast at world size 1 too (bench.py under OGG_FORCE_DIST=1: the
@@ -326,6 +326,7 @@ class SupergridPlan(object):
                 tail_us = float(os.environ["OGG_TOP_RANK_TAIL_US"])
             elif world > 1:
                 cap = 1.0 - world * tail_us / pass_us if world * tail_us / pass_us <= 0.5 else 1.0
+                tried = []                               # (slower of the two shares, share of the last rank) of every round
                 for _ in range(rounds):
                     self.set_split_times(tail_us, pass_us, "calibrating", top_capacity=(world, cap))
                     t = []
@@ -335,9 +336,13 @@ class SupergridPlan(object):
                         t.append(timed_us(h, 60, 150))
                         h.close()
                         del h
-                    cap = min(max(cap * t[0] / t[1], 0.3), 1.3)
+                    tried.append((max(t), cap))
                     if abs(t[0] / t[1] - 1.0) < 0.01:      # the two shares within 1 %: balanced as far as a timing can tell
                         break
+                    cap = min(max(cap * t[0] / t[1], 0.3), 1.3)
+                # the split whose slower share was fastest: a share's time is not always monotone in its size (tiling thresholds of the
+                # pass, the write path of some boxes), and then the last step of the iteration need not be its best
+                cap = min(tried)[1]
             torch.cuda.empty_cache()
             vals = (tail_us, pass_us, cap)
         if broadcast:   # three doubles from rank 0: a device tensor over RCCL, through the host where the group is gloo (as all_reduce does)
