@@ -147,11 +147,18 @@ def dp_cell(args):
     return j, i, out
 
 
-def dp_group(pool, quick):
-    nx, ny, lon0, lat0, lon_dp, lat_dp = 5760, 560, -300.0, -78.0, 80.0, -85.85
-    r_dp = float(np.tan((90 + lat_dp) * orc.PI_180) / np.tan((90 + lat0) * orc.PI_180))               # OGG:1160 (main's fp64 value: an INPUT)
-    jpole = (lat_dp + 90.0) / ((lat0 + 90.0) / ny)
-    kept = [276, 277, 278, 290, 310, 330, 350, 370, 390, 410, 430, 450, 470, 490, 510, 530, 545, 557, 558, 559]
+def dp_group(pool, quick, tag="dp"):
+    """tag "dp": the cap of BASELINE config 4 (1/8 degree, --lat_dp -85.85); "dp4": the cap of config 2 (OM4 1/4 degree, --r_dp 0.2), the
+    rows main() keeps after --south_cutoff_row 83 (native rows 220..279 of the 280) x every 11th column."""
+    if tag == "dp":
+        nx, ny, lon0, lat0, lon_dp, lat_dp = 5760, 560, -300.0, -78.0, 80.0, -85.85
+        r_dp = float(np.tan((90 + lat_dp) * orc.PI_180) / np.tan((90 + lat0) * orc.PI_180))           # OGG:1160 (main's fp64 value: an INPUT)
+        jpole = (lat_dp + 90.0) / ((lat0 + 90.0) / ny)
+        kept = [276, 277, 278, 290, 310, 330, 350, 370, 390, 410, 430, 450, 470, 490, 510, 530, 545, 557, 558, 559]
+    else:
+        nx, ny, lon0, lat0, lon_dp, r_dp = 2880, 280, -300.0, -78.0, 80.0, 0.2
+        jpole = float(np.arctan(r_dp * np.tan(12.0 * orc.PI_180)) / orc.PI_180 / (12.0 / ny))          # the row where r = r_pole
+        kept = [220, 221, 230, 240, 250, 260, 270, 277, 278, 279]
     polar = [int(jpole) - 1, int(jpole), int(jpole) + 1]
     cols_k = list(range(0, nx, 11))
     cols_p = list(range(0, nx, 44))
@@ -163,29 +170,29 @@ def dp_group(pool, quick):
     jobs = [(par, j, i, j1d[j], i1d[i]) for j in kept for i in cols_k] + [(par, j, i, j1d[j], i1d[i]) for j in polar for i in cols_p]
     t0 = time.time()
     res = pool.map(dp_cell, jobs, chunksize=16)
-    print("dp: %d cells in %.0f s" % (len(jobs), time.time() - t0), flush=True)
+    print("%s: %d cells in %.0f s" % (tag, len(jobs), time.time() - t0), flush=True)
     jj = np.array([r[0] for r in res])
     ii = np.array([r[1] for r in res])
     vals = np.array([r[2] for r in res])                      # (n, 6, 2): A dx dy area, B dx dy area; hi / lo
-    out = dict(dp_params=np.array([nx, ny, lon0, lat0, lon_dp, r_dp, 4.0]), dp_j=jj, dp_i=ii, dp_kept=np.isin(jj, kept),
-               dp_jpole=np.array(jpole))
+    out = {tag + "_params": np.array([nx, ny, lon0, lat0, lon_dp, r_dp, 4.0]), tag + "_j": jj, tag + "_i": ii, tag + "_kept": np.isin(jj, kept),
+           tag + "_jpole": np.array(jpole)}
     for k, name in enumerate(("A_dx", "A_dy", "A_area", "B_dx", "B_dy", "B_area")):
-        out["dp_" + name] = vals[:, k, :].copy()
+        out[tag + "_" + name] = vals[:, k, :].copy()
     # the oracle's own distance from the truth, row by row (whole lattice rows: the unwrap scan runs along i)
     eref = {n: 0.0 for n in ("A_dx", "A_dy", "A_area", "B_dx", "B_dy", "B_area")}
     for j in sorted(set(jj.tolist())):
         o = orc.displacedPoleCap_metrics_quad(4, nx, ny, lon0, lat0, lon_dp, r_dp, j_first=j, j_last=j + 1)
-        m = (jj == j) & out["dp_kept"]
+        m = (jj == j) & out[tag + "_kept"]
         if not m.any():
             continue
         for f, k in (("dx", 0), ("dy", 1), ("area", 2)):
             v = o[k][j, ii[m]]
             for T in "AB":
-                t = out["dp_%s_%s" % (T, f)][m]
+                t = out["%s_%s_%s" % (tag, T, f)][m]
                 eref["%s_%s" % (T, f)] = max(eref["%s_%s" % (T, f)], float(np.max(np.abs((v - t[:, 0]) - t[:, 1]) / np.abs(t[:, 0]))))
     for n, v in eref.items():
-        out["dp_%s_eref" % n] = np.array(v)
-        print("dp oracle vs truth %s: rel %.3e" % (n, v))
+        out["%s_%s_eref" % (tag, n)] = np.array(v)
+        print("%s oracle vs truth %s: rel %.3e" % (tag, n, v))
     return out
 
 
@@ -434,6 +441,7 @@ def main():
         out.update(bq_group(pool, a.quick))
         out.update(bp_group(pool, a.quick))
         out.update(dp_group(pool, a.quick))
+        out.update(dp_group(pool, a.quick, "dp4"))
     path = a.out if not a.quick else "/tmp/truth_table_quick.npz"
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

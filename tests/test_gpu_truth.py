@@ -57,10 +57,13 @@ def stats(e, scale):
 # ---------------------------------------------------------------------------------------------------------------
 # OGG:522-601: displaced-pole quadrature of finite-difference scale factors, cap of BASELINE config 4
 # ---------------------------------------------------------------------------------------------------------------
-def test_displaced_pole_quadrature_vs_truth(ogg, truth):
-    nx, ny, lon0, lat0, lon_dp, r_dp, order = truth["dp_params"]
+@pytest.mark.parametrize("tag", ["dp", "dp4"])
+def test_displaced_pole_quadrature_vs_truth(ogg, truth, tag):
+    """tag dp: the cap of BASELINE config 4 (1/8 degree, --lat_dp -85.85), 10 480 cells of the kept rows + 393 around r = r_pole; dp4: the cap
+    of config 2 (OM4 1/4 degree, --r_dp 0.2), 2620 cells of the rows that survive --south_cutoff_row 83 + 198 around r = r_pole."""
+    nx, ny, lon0, lat0, lon_dp, r_dp, order = truth[tag + "_params"]
     nx, ny, order = int(nx), int(ny), int(order)
-    jj, ii, kept = truth["dp_j"], truth["dp_i"], truth["dp_kept"]
+    jj, ii, kept = truth[tag + "_j"], truth[tag + "_i"], truth[tag + "_kept"]
     lit = ogg.displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, arc_form="literal")
     cho = ogg.displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, arc_form="chord")
     o = [np.zeros(jj.size) for _ in range(3)]
@@ -70,27 +73,27 @@ def test_displaced_pole_quadrature_vs_truth(ogg, truth):
         for k in range(3):
             o[k][m] = row[k][j, ii[m]]
     rep = {}
-    for grp, m in (("kept_rows_276_559", kept), ("rows_around_r_pole", ~kept)):
+    for grp, m in (("kept_rows", kept), ("rows_around_r_pole", ~kept)):
         for k, f in enumerate(("dx", "dy", "area")):
             vo, vl, vc = o[k][m], lit[k][jj[m], ii[m]], cho[k][jj[m], ii[m]]
             e = {"n": int(m.sum())}
             for T in "AB":
-                t = truth["dp_%s_%s" % (T, f)][m]
+                t = truth["%s_%s_%s" % (tag, T, f)][m]
                 e["oracle_vs_truth" + T] = stats(err(vo, t), t[:, 0])
                 e["hip_literal_vs_truth" + T] = stats(err(vl, t), t[:, 0])
                 e["hip_chord_vs_truth" + T] = stats(err(vc, t), t[:, 0])
             e["hip_literal_vs_oracle"] = stats(np.abs(vl - vo), vo)
             e["hip_chord_vs_oracle"] = stats(np.abs(vc - vo), vo)
             e["hip_chord_vs_hip_literal"] = stats(np.abs(vc - vl), vl)
-            tA, tB = truth["dp_A_%s" % f][m], truth["dp_B_%s" % f][m]
+            tA, tB = truth["%s_A_%s" % (tag, f)][m], truth["%s_B_%s" % (tag, f)][m]
             e["truthA_vs_truthB"] = stats(np.abs((tA[:, 0] - tB[:, 0]) + (tA[:, 1] - tB[:, 1])), tA[:, 0])
             rep["%s/%s" % (grp, f)] = e
-    REPORT["dp_quadrature_OGG522_601"] = rep
+    REPORT["dp_quadrature_OGG522_601" + ("" if tag == "dp" else "_om4_cap")] = rep
     _save()
     for f in ("dx", "dy", "area"):
-        e = rep["kept_rows_276_559/" + f]
+        e = rep["kept_rows/" + f]
         for T in "AB":
-            eref = float(truth["dp_%s_%s_eref" % (T, f)])
+            eref = float(truth["%s_%s_%s_eref" % (tag, T, f)])
             # the oracle on THIS host reproduces the fixture's own measurement (same image: same libm); on another libm it stays of that size
             assert e["oracle_vs_truth" + T]["max_rel"] <= 2.0 * eref, (f, T)
             assert e["hip_literal_vs_truth" + T]["max_rel"] <= K_REF * eref, (f, T, e["hip_literal_vs_truth" + T], eref)
