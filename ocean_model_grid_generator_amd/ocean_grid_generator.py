@@ -436,7 +436,7 @@ def mdist(x1, x2):
 
 
 def generate_grid_metrics_MIDAS(x, y, axis_units="degrees", Re=_default_Re, latlon_areafix=True):
-    """OGG:687-716 (kernel midas_angle_kernel)."""
+    """OGG:687-716 (kernel midas_tile_kernel: an LDS-staged tile walk, csrc/ogg_midas.hip)."""
     x, y = _f64(x), _f64(y)
     if x.shape != y.shape:
         raise Exception("Input arrays do not have the same shape!")

@@ -61,3 +61,25 @@ def test_plain_invocation_without_gpus_fails_loudly():
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert "torch.distributed.run with 2 ranks failed" in p.stderr
+
+
+def test_self_launch_retries_once_when_the_port_was_taken(monkeypatch, capfd, tmp_path):
+    """The rendezvous port is chosen by binding and closing a socket; somebody else may take it before torch.distributed.run binds it.
+    A child that dies with 'Address already in use' is started once more on another port; a second such failure is reported."""
+    b = _bench()
+    line = json.dumps({"metric": "m", "n_gpus": 2})
+    marker = tmp_path / "first"
+    child = ("import sys, os\n"
+             "p = %r\n"
+             "if not os.path.exists(p):\n"
+             "    open(p, 'w').close(); sys.stderr.write('RuntimeError: The server socket has failed to listen ... EADDRINUSE Address already in use\\n'); sys.exit(1)\n"
+             "print(%r)\n" % (str(marker), line))
+    ports = []
+    monkeypatch.setattr(b, "self_launch_command", lambda n, argv, port: (ports.append(port), [sys.executable, "-c", child])[1])
+    assert b.self_launch(2, []) == 0
+    out, err = capfd.readouterr()
+    assert out.strip().splitlines() == [line] and len(ports) == 2 and "once more with another port" in err
+    always = "import sys; sys.stderr.write('Address already in use\\n'); sys.exit(1)"
+    monkeypatch.setattr(b, "self_launch_command", lambda n, argv, port: [sys.executable, "-c", always])
+    assert b.self_launch(2, []) == 1
+    assert "failed (exit code 1)" in capfd.readouterr()[1]
