@@ -412,12 +412,25 @@ def main():
     for _ in range(60):  # a fixed count: in the stencil pipeline every pass holds a neighbour exchange
         sg.run_pass()
     torch.cuda.synchronize()
+    if args.latlon == "fused":
+        # ... and for at least 60 ms: the clocks of a fresh process take ~30 ms of WORK to ramp, and one rank of eight does 60 passes in
+        # 2 ms (no collective in a fused pass: every rank may run its own count)
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.06:
+            for _ in range(20):
+                sg.run_pass()
+            torch.cuda.synchronize()
     sg.launch = "kernels"
     can_graph = not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
     use_graph = bool(args.graph) and can_graph
     tuned = None
     has_dp = any(s.kind == "dpole" for s in plan.subs)
-    if args.latlon == "fused" and args.launch == "auto":
+    if args.latlon == "fused" and args.launch == "auto" and world > 1:
+        # several ranks: the fused pass, which exists for small shares (a side stream's dependency costs 10-20 us, as much as a rank's
+        # kernels at 8 ranks); a 30-pass timing of a 40 us share is too noisy to choose by (a rehearsal picked "kernels" for one rank of
+        # four and made it the slowest)
+        sg.launch, sg.overlap, use_graph = "pass", False, False
+    elif args.latlon == "fused" and args.launch == "auto":
         # set-up, untimed: every rank keeps the launch scheme that is fastest for ITS share (there is no collective in a pass)
         tuned = {}
         # (the pass is launched eagerly: a graph of its three launches gains nothing and would hide them from the events)
