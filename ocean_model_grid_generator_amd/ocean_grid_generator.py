@@ -441,6 +441,11 @@ def generate_grid_metrics_MIDAS(x, y, axis_units="degrees", Re=_default_Re, latl
     if x.shape != y.shape:
         raise Exception("Input arrays do not have the same shape!")
     nj1, ni1 = x.shape
+    if nj1 == 1 and ni1 >= 2:
+        # a single row of points: numpy's slices give dx (1, ni1-1) and EMPTY dy, area.  dx of a row depends on that row alone, so the
+        # kernel runs on the row taken twice and its first dx row is the answer (the library's own entry wants two rows of points)
+        dx2, _, _ = generate_grid_metrics_MIDAS(np.concatenate((x, x), axis=0), np.concatenate((y, y), axis=0), axis_units, Re, latlon_areafix)
+        return np.ascontiguousarray(dx2[:1]), _new(0, ni1), _new(0, ni1 - 1)
     dx, dy, area = _new(nj1, ni1 - 1), _new(nj1 - 1, ni1), _new(nj1 - 1, ni1 - 1)
     L.call("ogg_grid_metrics_midas", nj1, ni1, L.ptr(x), L.ptr(y), float(Re), int(bool(latlon_areafix)), L.ptr(dx), L.ptr(dy),
            L.ptr(area))
