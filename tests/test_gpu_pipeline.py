@@ -75,6 +75,30 @@ def test_band_decomposition_is_bit_invariant(sg, name, world, halo):
         assert np.array_equal(one[f], many[f]), (f, world, halo)
 
 
+@pytest.mark.parametrize("name,world", [("r2", 8), ("r2", 3), ("r0.5_dp", 4), ("r1_cut2", 2)])
+def test_measured_split_keeps_the_bits(sg, name, world):
+    """SupergridPlan.calibrate_split on this GPU (one process: no broadcast): the last rank's share comes out of timings, so the band
+    edges differ from run to run and from box to box -- the stitched fields must not.  The measured share is in effect (rows_of follows
+    it), every row is covered once, and the fused pass over the measured bands gives the single-rank bits."""
+    plan = plan_for(sg, name)
+    one = run_pass_mode(sg, plan, 1)
+    st = plan.calibrate_split("cuda:0", rank=0, world=world, broadcast=False, rounds=2)
+    if plan.skip_metrics or not any(s.kind == "bipolar" for s in plan.subs):
+        assert st is None
+    else:
+        assert "measured by rank 0" in st["source"] and st["top_capacity"]["world"] == world and 0.3 <= st["top_capacity"]["share_of_last_rank"] <= 1.3
+        assert 0 < st["tail_us"] < st["pass_us"]
+    for s in plan.subs:
+        rows = []
+        for r in range(world):
+            lo, hi = sg.Supergrid.rows_of(s, r, world)
+            rows += list(range(lo, hi))
+        assert rows == list(range(s.nj1)), s.name
+    many = run_pass_mode(sg, plan, world)
+    for f in FIELDS:
+        assert np.array_equal(one[f], many[f], equal_nan=False), (f, world)
+
+
 @pytest.mark.parametrize("name", ["r1_cut2", "r2", "r2_skip_metrics", "r0.5_dp", "r0.25_even"])
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_fused_latlon_kernel_is_bit_identical_to_stencil(sg, name, world):
