@@ -71,62 +71,54 @@ def band_points(plan, rank, world, sg_mod):
     return pts
 
 
-def cpu_baseline(flags, sample_div, per_cell_loop=False):
-    """Oracle timed on the southernmost 1/sample_div of the rows of every sub-grid (1 thread, like the reference).
+def cpu_baseline(plan, sample_div, per_cell_loop=False):
+    """Oracle timed on the southernmost 1/sample_div of the kept rows of every sub-grid of `plan` (1 thread, like the reference).  Every
+    size comes from the plan's host-only attributes (Ni, axes, lat0_bp, Nj, the cap's kept rows after the doughnut and the south cuts),
+    so the cells counted are the cells of the benched grid: with sample_div == 1 exactly plan.cells.
     ``per_cell_loop``: the quadratures average cell by cell in Python like the reference (OGG:176-187, 585-599) instead of
     vectorised over the chunk -- the "reference-shaped" row of SURVEY 8(d)."""
     from oracle import ogg_oracle as orc
 
-    r = flags["inverse_resolution"]
-    Ni = int(r * 2 * 360)
-    q = Ni // 4
+    Ni = plan.Ni
     t0 = time.perf_counter()
     cells = 0
-    phi_s, phi_n = (-68.0, 65.0) if r == 2 else (-66.85954725, 64.05895973)
-    y0, y1 = orc.mercator_y_star(Ni, phi_s, phi_n, True, False)
-    phi_M = orc.phi_mercator(Ni, np.arange(y0, y1 + 1))
-    lam = -300.0 + np.arange(Ni + 1) * 360 / float(Ni)
+    lam = plan.lon0 + np.arange(Ni + 1) * plan.lenlon / float(Ni)
 
-    def latlon_band(axis):
-        n = max((axis.size - 1) // sample_div, 1)
-        x = np.tile(lam, (n + 1, 1))
-        y = np.tile(axis[: n + 1].reshape(-1, 1), (1, Ni + 1))
-        orc.generate_grid_metrics_MIDAS(x, y)
-        orc.angle_x(x, y)
-        return n * Ni
+    def sample_rows(s):   # cell rows of the sample: the southernmost 1/div of the sub-grid's kept cell rows, at least one
+        return max((s.nj1 - 1) // sample_div, 1) if s.nj1 > 1 else 0
 
-    cells += latlon_band(phi_M)
-    lat0_bp = phi_M[-1]
-    Nj = int(60 * r * 2) if r != 2 else 238
-    n = max(Nj // sample_div, 1)
-    lon_g = -300.0 + np.arange(Ni + 1) * 360.0 / float(Ni)
-    latg = lat0_bp + np.arange(n + 1) * (90 - lat0_bp) / float(Nj)
-    rp = np.tan(0.5 * (90 - lat0_bp) * orc.PI_180)
-    lams, phis, _, _ = orc.bipolar_projection(np.tile(lon_g, (n + 1, 1)), np.tile(latg.reshape(-1, 1), (1, Ni + 1)), -300.0, rp)
-    orc.angle_x(lams, phis)
-    orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0_bp, -300.0, rp, rows_per_chunk=16, j_last=n, per_cell_loop=per_cell_loop)
-    cells += n * Ni
-    latUp = phi_M[0]
-    so_axis = -78.0 + np.arange(int(r * 55) + 1) * (latUp + 78.0) / float(int(r * 55))
-    cells += latlon_band(so_axis)
-    if flags.get("lat_dp", -99.0) > -90 or flags.get("r_dp", 0.0) != 0.0:
-        Njs = int(r * 40) * 7 // 4
-        r_dp = flags.get("r_dp", 0.0)
-        if flags.get("lat_dp", -99.0) > -90:
-            r_dp = np.tan((90 + flags["lat_dp"]) * orc.PI_180) / np.tan((90 - 78.0) * orc.PI_180)
-        jm = int(np.ceil(0.49 * Njs))
-        jm += jm % 2
-        n = max((Njs - jm) // sample_div, 1)
-        x, y, _, _ = orc.displacedPoleCap_mesh(np.arange(Ni + 1), np.arange(jm, jm + n + 1), Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp)
-        orc.angle_x(x, y)
-        orc.displacedPoleCap_metrics_quad(4, Ni, Njs, -300.0, -78.0, flags.get("lon_dp", 80.0), r_dp, rows_per_chunk=8, j_first=jm, j_last=jm + n,
-                                          per_cell_loop=per_cell_loop)
+    for s in plan.subs:
+        n = sample_rows(s)
+        if n == 0:
+            continue
+        if s.kind in ("mercator", "latlon"):
+            if s.kind == "mercator":
+                axis = s.explicit_axis if getattr(s, "explicit_axis", None) is not None else orc.phi_mercator(Ni, np.arange(s.y0, s.y0 + s.n_axis))
+            else:
+                axis = s.lat0 + np.arange(s.lnj + 1) * s.lenlat / float(s.lnj)
+            axis = np.asarray(axis)[s.row0:s.row0 + n + 1]
+            x = np.tile(lam, (n + 1, 1))
+            y = np.tile(axis.reshape(-1, 1), (1, Ni + 1))
+            if not plan.skip_metrics:
+                orc.generate_grid_metrics_MIDAS(x, y)
+            orc.angle_x(x, y)
+        elif s.kind == "bipolar":
+            latg = s.lat0_bp + np.arange(s.row0, s.row0 + n + 1) * (90 - s.lat0_bp) / float(s.Nj)
+            lams, phis, _, _ = orc.bipolar_projection(np.tile(lam, (n + 1, 1)), np.tile(latg.reshape(-1, 1), (1, Ni + 1)), s.lon_bp, s.rp)
+            orc.angle_x(lams, phis)
+            if not plan.skip_metrics:
+                orc.bipolar_cap_metrics_quad_fast(5, Ni, s.Nj, s.lat0_bp, s.lon_bp, s.rp, rows_per_chunk=16, j_first=s.row0, j_last=s.row0 + n,
+                                                  per_cell_loop=per_cell_loop)
+        else:   # displaced-pole cap: the rows main() keeps (behind the doughnut, OGG:1177-1186, and the south cut)
+            x, y, _, _ = orc.displacedPoleCap_mesh(np.arange(Ni + 1), np.arange(s.row0, s.row0 + n + 1), Ni, s.Nj, plan.lon0, s.lat0, s.lon_dp, s.r_dp)
+            orc.angle_x(x, y)
+            if not plan.skip_metrics:
+                orc.displacedPoleCap_metrics_quad(4, Ni, s.Nj, plan.lon0, s.lat0, s.lon_dp, s.r_dp, rows_per_chunk=8, j_first=s.row0,
+                                                  j_last=s.row0 + n, per_cell_loop=per_cell_loop)
         cells += n * Ni
-    else:
-        Njs = int((-78.0 + 90.0) / (1.0 / r / 2))
-        sc_axis = -90.0 + np.arange(Njs + 1) * 12.0 / float(Njs)
-        cells += latlon_band(sc_axis)
     dt = time.perf_counter() - t0
+    if sample_div == 1:
+        assert cells == plan.cells, (cells, plan.cells)
     return cells, dt
 
 
@@ -466,14 +458,17 @@ def main():
     # (on the launch stream, by the library itself): the per-launch durations of the roofline object come from the timed region.
     sample = sg.launch == "pass" and not use_graph
     # 2-3 sampled passes: the event records cost ~7 us per sampled pass, and a sampled pass runs its table launch itself (~4 us) instead of
-    # finding its tables built by the previous pass's launch B.  One rank: they are 2-3 of the K timed passes.  Several ranks (a rank's K
-    # passes are a fraction of a millisecond at 8 ranks): they run right AFTER the timed region, which then holds K plain passes.
-    sample_inside = sample and world == 1
+    # finding its tables built by the previous pass's launch B.  They run right AFTER the timed region, which holds K plain passes -- at
+    # every N (round 4 kept them inside at N = 1 only: two definitions of the region on one scaling curve)
+    sample_inside = False
     stride = max(1, args.steps // 2)
     if sample:
         sg.reserve_pass_events(args.steps // stride + 1)
         events = []
     carried0 = sg.pass_plan_info()[1]
+    # the region on three host clocks: scripts/trace_window.py finds the K timed launches in a rocprofv3 kernel trace of this command by them
+    clocks = {"monotonic": time.CLOCK_MONOTONIC, "boottime": getattr(time, "CLOCK_BOOTTIME", time.CLOCK_MONOTONIC), "realtime": time.CLOCK_REALTIME}
+    region_ns = {k: [time.clock_gettime_ns(c)] for k, c in clocks.items()}
     t0 = time.perf_counter()
     for k in range(args.steps):
         if use_graph:
@@ -485,7 +480,10 @@ def main():
     torch.cuda.synchronize()
     # This rank's own K passes, from the opening barrier + synchronize to ITS synchronize.  A pass has no inter-rank dependency (no
     # collective, no halo in the default pipeline), so the job's wall time is the MAX of this over the ranks: that is `value`.
-    dt_local = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    dt_local = t_end - t0
+    for k, c in clocks.items():
+        region_ns[k].append(time.clock_gettime_ns(c))
     if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
@@ -502,12 +500,15 @@ def main():
         sg.pass_events = events
         launches = sg.pass_launch_times_ms()
         sg.pass_events = None
+    # `value`: the JOB's wall time for its K passes = latest end over the ranks - earliest start over the ranks, on the node's common
+    # monotonic clock (one node: every rank reads the same CLOCK_MONOTONIC) -- the ranks leave the opening barrier a few microseconds
+    # apart, so this is >= every rank's own elapsed time; the same expression at N = 1 is that rank's elapsed time
     dt = dt_slowest = dt_local
     if use_dist:
-        t = torch.tensor([dt_barrier, dt_local], dtype=torch.float64, device=device)
+        t = torch.tensor([dt_barrier, dt_local, -t0, t_end], dtype=torch.float64, device=device)
         supergrid.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_barrier, dt_slowest = float(t[0].item()), float(t[1].item())
-        dt = dt_slowest
+        dt = float(t[3].item()) + float(t[2].item())   # max(end) - min(start)
     # self-check, untimed: the reference's CHECK_metrics numbers (OGG:732-770) for the bands now in HBM -- five sums per band on the
     # device and one all-reduce (RCCL) of n_subs x 7 doubles, the only collective of the default pipeline
     self_check = None
@@ -663,6 +664,9 @@ def main():
                     rv = {"kernel": kn, "valu_busy_frac": round(vc["valu_busy_frac"], 4), "wave64_valu_instr_per_launch": vc["wave64_valu_instr"],
                           "source": "profiles/valu_counters.json (builder-side rocprofv3 --pmc run, committed; same kernel sources as the loaded library)"}
                 roof = valu_bound_roofline(roof, rv, kernels[dom]["mean_ms"])
+        # the number nobody can dispute: every field of the step written once (48 B per cell) over the step's own wall time, per GPU
+        roof["frac_step"] = round(48.0 * plan.cells * args.steps / dt / 1e9 / (HBM_PEAK_GBS * world), 4)
+        roof["frac_step_note"] = "48 B x cells / ms_per_step / (n_gpus x 8 TB/s): the whole step, launch gaps and the fix-up launch included"
         out = {
             "metric": METRIC, "value": plan.cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if use_dist else 1), "per_rank": per_rank,
@@ -671,8 +675,10 @@ def main():
             "ms_per_step_slowest_rank": dt_slowest / args.steps * 1e3,
             # the same region through a closing barrier + synchronize (max over ranks): what round 1-3 reported as `ms_per_step`
             "ms_per_step_with_closing_barrier": dt_barrier / args.steps * 1e3,
-            "timing": "K passes between an opening barrier + synchronize and each rank's own synchronize, max over ranks (a pass holds no "
-                      "inter-rank dependency); launch events %s" % ("of 2-3 of the K passes" if sample_inside else "of extra passes right after the region"),
+            "timing": "K plain passes between an opening barrier + synchronize and each rank's own synchronize; `value` from the latest end "
+                      "minus the earliest start over the ranks on the node's monotonic clock (a pass holds no inter-rank dependency; the same "
+                      "definition at every N); launch events of 2-3 extra passes right after the region",
+            "timed_region_clock_ns": region_ns,
             # fused pass: of the K timed passes, how many started with launch B because the previous pass's launch B had built their
             # tables (every pass builds one set of tables; the passes that record events run launch A themselves) -- DESIGN.md 4.1
             "pass_plan": {"workspace_slots": plan_slots, "timed_passes_whose_tables_rode_in_the_previous_launch_b": carried1 - carried0},
@@ -704,14 +710,14 @@ def main():
                                          ("; below that, " + roof["limited_by"]) if roof.get("limited_by") else ""))
         out["cpu_baseline"] = None   # timed on rank 0 of a one-GPU run only (and not with --cpu-sample-div 0)
         if world == 1 and args.cpu_sample_div > 0:
-            cells, cdt = cpu_baseline(flags, args.cpu_sample_div)
+            cells, cdt = cpu_baseline(plan, args.cpu_sample_div)
             out["cpu_baseline"] = {"value": cells / cdt, "unit": "cells/s", "cores": 1, "kind": "port",
                                    "sample": "numpy oracle on the southernmost 1/%d of the rows of every sub-grid of the same "
                                              "workload: %d cells in %.1f s" % (args.cpu_sample_div, cells, cdt),
                                    "host_cpus": os.cpu_count()}
             # the same span with the reference's per-cell Python loops in the quadratures, on a smaller sample (a few seconds)
             rs_div = max(64, args.cpu_sample_div)
-            cells2, cdt2 = cpu_baseline(flags, rs_div, per_cell_loop=True)
+            cells2, cdt2 = cpu_baseline(plan, rs_div, per_cell_loop=True)
             out["cpu_baseline_reference_shaped"] = {
                 "value": cells2 / cdt2, "unit": "cells/s", "cores": 1, "kind": "port",
                 "sample": "as cpu_baseline but the quadratures average cell by cell in Python like the reference (OGG:176-187, 585-599); "

@@ -31,6 +31,19 @@ extern "C" {
 #define OGG_DP_ARC_LITERAL 0 /* arc form of the displaced-pole quadrature: see ogg_displaced_pole_metrics_quad_form_ws_dev */
 #define OGG_DP_ARC_CHORD 1
 
+/* Mirror symmetry of the two caps (the `symmetry` field of ogg_bipolar_band / ogg_dpole_band, the *_sym_* entry points).
+ *   OGG_SYM_MIRROR  evaluate the columns that determine the rest and write their mirror images: the bipolar projection (OGG:33-100) is
+ *                   symmetric about its two pole meridians and its fold lines, so a quarter of the columns determines a row; the
+ *                   displaced-pole map (OGG:447-467) about the meridian through lon_dp, so half of them does.  The columns where the
+ *                   reference's own results are not mirror images of each other to within its own rounding error (next to the fold
+ *                   lines, the pole meridians of the mesh, the rows next to the pole points) are still evaluated one by one: DESIGN.md.
+ *   OGG_SYM_NONE    every column evaluated, as the reference does (OGG:168-172, 583-584).
+ *   OGG_SYM_DEFAULT (0, what a zero-initialised descriptor asks for) the library's default: OGG_SYM_MIRROR unless the environment says
+ *                   OGG_CAP_SYMMETRY=0 / none. */
+#define OGG_SYM_DEFAULT 0
+#define OGG_SYM_MIRROR 1
+#define OGG_SYM_NONE 2
+
 const char* ogg_last_error(void);
 /* "ogg_hip <version> (gfx950) src <hash>": <hash> = first 12 hex digits of the sha256 over the kernel sources the library was built
  * from (csrc/build.py source_hash()); profiles/valu_counters.json and hbm_traffic.json record the hash they were collected with */
@@ -151,8 +164,15 @@ int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, lo
 /* same, also writing angle_dx = angle_x(lams, phis) (nrows x (Ni+1); NULL to skip) without reading the mesh back */
 int ogg_bipolar_cap_mesh_angle_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
                                    double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream);
+/* same with the column symmetry stated by the caller (OGG_SYM_*; the forms above ask for OGG_SYM_DEFAULT): mirrored, the columns
+ * [0, Ni/4] (+ 2 degrees beyond the pole meridian) are evaluated and written to their three images, the columns next to the fold lines
+ * and within 2 degrees of the pole meridians at their own positions */
+int ogg_bipolar_cap_mesh_angle_sym_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, int symmetry, double* lams,
+                                       double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream);
 int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis,
                          double* h_i_inv, double* h_j_inv);
+int ogg_bipolar_cap_mesh_sym(long Ni, long Nj, double lat0_bp, double lon_bp, int symmetry, double* lams, double* phis,
+                             double* h_i_inv, double* h_j_inv);
 
 /* bipolar_cap_ij_array (OGG:125-133): per-index arc lengths (radians) at fractional indices i[n_i], j[n_j];
  * h_i_inv, h_j_inv: n_j x n_i */
@@ -169,6 +189,8 @@ int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp
                                      double* daq, void* stream);
 int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
                                  double* dxq, double* dyq, double* daq);
+int ogg_bipolar_cap_metrics_quad_sym(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re, int symmetry,
+                                     double* dxq, double* dyq, double* daq);
 /* Same with a caller-provided device workspace for the row/column tables (at least ogg_bipolar_quad_workspace_bytes
  * bytes): no allocation of any kind inside the call, so it can be captured into a HIP graph.  The plain _dev form takes
  * the tables from the stream-ordered allocator (hipMallocAsync / hipFreeAsync). */
@@ -176,6 +198,12 @@ long ogg_bipolar_quad_workspace_bytes(int order, long nx, long ny);
 int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
                                         long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
                                         void* workspace, long workspace_bytes, void* stream);
+/* Same with the column symmetry stated by the caller (OGG_SYM_*, top of this file); the forms above ask for OGG_SYM_DEFAULT.  Mirrored,
+ * the rows below 88.2 degrees are evaluated on the cells [0, nx/4) and next to the fold lines (6 degrees either side of the columns
+ * 0 and nx/2) and written to their images; replaces the column loop of OGG:168-172 for those rows. */
+int ogg_bipolar_cap_metrics_quad_sym_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                            long j0, long n_dx_rows, long n_cell_rows, int symmetry, double* dxq, double* dyq, double* daq,
+                                            void* workspace, long workspace_bytes, void* stream);
 
 /* One rank's share of a tripolar supergrid -- the lat-lon sub-grids and the bipolar cap generated by the sub-grid loop of
  * main() (OGG:1100-1313: generate_mercator_grid / generate_latlon_grid / generate_bipolar_cap_mesh + angle_x +
@@ -188,6 +216,7 @@ typedef struct ogg_bipolar_band {
     double lat0_bp, lon_bp;  /* OGG:103 */
     double rp, Re;           /* OGG:117; sphere radius */
     int order;               /* Gauss-Lobatto order of the quadrature, 2..5 (OGG:191-204) */
+    int symmetry;            /* OGG_SYM_DEFAULT (0), OGG_SYM_MIRROR or OGG_SYM_NONE: mesh and quadrature from a quarter of the columns */
     long j0;                 /* first mesh row of the band */
     long n_pt_rows;          /* point rows: x, y, angle (n_pt_rows x (Ni+1)), dx (n_pt_rows x Ni) */
     long n_cell_rows;        /* cell rows: dy (n_cell_rows x (Ni+1)), area (n_cell_rows x Ni); n_pt_rows - 1 on the band that
@@ -290,10 +319,19 @@ int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx
                                                 double lon_dp, double r_dp, double Re, long j0, long n_dx_rows,
                                                 long n_cell_rows, double* dxq, double* dyq, double* daq, void* workspace,
                                                 long workspace_bytes, void* stream);
+/* same with the column symmetry stated by the caller (OGG_SYM_*; the form above asks for OGG_SYM_DEFAULT).  Mirrored (chord form only, when
+ * the meridian of the displaced pole is a node column, (lon_dp - lon0) nx / 360 an integer, and nx is even): the half of the columns on
+ * one side of that meridian is evaluated and written to its mirror images (OGG:583-584 evaluate every column) */
+int ogg_displaced_pole_metrics_quad_form_sym_ws_dev(int arc_form, int symmetry, int order, long nx, long ny, double lon0, double lat0,
+                                                    double lon_dp, double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
+                                                    double* dxq, double* dyq, double* daq, void* workspace, long workspace_bytes,
+                                                    void* stream);
 int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
                                     double Re, double* dxq, double* dyq, double* daq);
 int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
                                          double r_dp, double Re, double* dxq, double* dyq, double* daq);
+int ogg_displaced_pole_metrics_quad_form_sym(int arc_form, int symmetry, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                             double r_dp, double Re, double* dxq, double* dyq, double* daq);
 
 /* One rank's share of a whole supergrid: ogg_tripolar_pass_dev plus the band of a displaced-pole southern cap (the SC branch of
  * the same sub-grid loop, OGG:1158-1197: generate_displaced_pole_grid + angle_x + displacedPoleCap_metrics_quad) in the SAME
@@ -316,8 +354,15 @@ typedef struct ogg_dpole_band {
     double *x, *y, *angle, *dx, *dy, *area;
     void* workspace;             /* >= ogg_dpole_band_workspace_bytes(order, Ni, n_pt_rows) bytes of device memory */
     long workspace_bytes;
+    int symmetry;                /* OGG_SYM_DEFAULT (0), OGG_SYM_MIRROR or OGG_SYM_NONE: the chord-form quadrature from half of the columns */
 } ogg_dpole_band;
 long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows);
+/* Host-side check of the mirrored kernels' column spaces (no GPU): replays the index arithmetic the kernels use for one row of a cap with n
+ * cells -- which = 0 the bipolar quadrature, 1 the bipolar mesh, 2 the displaced-pole quadrature in the chord form (order 2 or 4; lon0,
+ * lon_dp: the meridian of the displaced pole) -- and counts how often every cell (cell_writes[n]; NULL for which = 1) and every node column
+ * (col_writes[n + 1]) is written, and how many are evaluated.  Every count must be 1 whatever `symmetry` (OGG_SYM_*). */
+int ogg_symmetry_coverage(int which, int order, long n, double lon0, double lon_dp, int symmetry, int* cell_writes, int* col_writes,
+                          long* evaluated);
 int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
                            const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, void** events5, double* alg_bytes4,
                            void* stream);

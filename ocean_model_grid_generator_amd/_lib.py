@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("OGG_LIB_PATH") or os.path.join(_HERE, "csrc", "libogg
 
 OGG_OK, OGG_EORDER, OGG_ESHAPE, OGG_EHIP, OGG_ENOMEM, OGG_EARG = 0, 1, 2, 3, 4, 5
 DP_ARC_LITERAL, DP_ARC_CHORD = 0, 1   # OGG_DP_ARC_* of include/ogg_hip.h
+SYM_DEFAULT, SYM_MIRROR, SYM_NONE = 0, 1, 2   # OGG_SYM_* of include/ogg_hip.h
 
 c_long, c_int, c_double, c_void_p, c_longlong = ctypes.c_long, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_longlong
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -29,8 +30,8 @@ class LatlonBand(ctypes.Structure):
 class BipolarBand(ctypes.Structure):
     """ogg_bipolar_band of include/ogg_hip.h"""
     _fields_ = [("Ni", c_long), ("Nj", c_long), ("lat0_bp", c_double), ("lon_bp", c_double), ("rp", c_double), ("Re", c_double),
-                ("order", c_int), ("j0", c_long), ("n_pt_rows", c_long), ("n_cell_rows", c_long), ("x", c_void_p), ("y", c_void_p),
-                ("angle", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p), ("workspace", c_void_p),
+                ("order", c_int), ("symmetry", c_int), ("j0", c_long), ("n_pt_rows", c_long), ("n_cell_rows", c_long), ("x", c_void_p),
+                ("y", c_void_p), ("angle", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p), ("workspace", c_void_p),
                 ("workspace_bytes", c_long)]
 
 
@@ -39,7 +40,7 @@ class DpoleBand(ctypes.Structure):
     _fields_ = [("Ni", c_long), ("Nj", c_long), ("lon0", c_double), ("lat0", c_double), ("lon_dp", c_double), ("r_dp", c_double),
                 ("Re", c_double), ("order", c_int), ("arc_form", c_int), ("j0", c_long), ("n_pt_rows", c_long), ("n_cell_rows", c_long),
                 ("x", c_void_p), ("y", c_void_p), ("angle", c_void_p), ("dx", c_void_p), ("dy", c_void_p), ("area", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_long)]
+                ("workspace", c_void_p), ("workspace_bytes", c_long), ("symmetry", c_int)]
 
 
 # name -> argtypes; every function returns int except the two string getters.  Must list EVERY symbol of ogg_hip.h
@@ -68,11 +69,20 @@ SIGNATURES = {
                                  c_void_p],
     "ogg_bipolar_cap_mesh_angle_dev": [c_long, c_long, c_double, c_double, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p],
+    "ogg_bipolar_cap_mesh_sym": [c_long, c_long, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ogg_bipolar_cap_metrics_quad_sym": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p],
+    "ogg_displaced_pole_metrics_quad_form_sym": [c_int, c_int, c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double, c_void_p,
+                                                 c_void_p, c_void_p],
+    "ogg_symmetry_coverage": [c_int, c_int, c_long, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p],
+    "ogg_bipolar_cap_mesh_angle_sym_dev": [c_long, c_long, c_double, c_double, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p],
     "ogg_bipolar_cap_mesh": [c_long, c_long, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_bipolar_cap_metrics_quad_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_long,
                                          c_void_p, c_void_p, c_void_p, c_void_p],
     "ogg_bipolar_cap_metrics_quad_ws_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_long,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ogg_bipolar_cap_metrics_quad_sym_ws_dev": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_long, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ogg_bipolar_cap_metrics_quad": [c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
                                      c_void_p],
     "ogg_displaced_pole_mesh_dev": [c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_double, c_double, c_double,
@@ -95,6 +105,8 @@ SIGNATURES = {
                                              c_void_p, c_void_p],
     "ogg_displaced_pole_metrics_quad_form_ws_dev": [c_int, c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double,
                                                     c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ogg_displaced_pole_metrics_quad_form_sym_ws_dev": [c_int, c_int, c_int, c_long, c_long, c_double, c_double, c_double, c_double, c_double,
+                                                        c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ogg_displaced_pole_grid_angle_ws_dev": [c_long, c_long, c_double, c_double, c_double, c_double, c_long, c_long, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ogg_workspace_error_flag_dev": [c_void_p, ctypes.POINTER(c_int), c_void_p],
@@ -183,6 +195,8 @@ def load():
             pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
+        if os.environ.get("OGG_LIB_PATH") and not hasattr(lib, name):
+            continue   # an older build under A/B timing (scripts/ab_time.py): the entry points it lacks are not called there
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int

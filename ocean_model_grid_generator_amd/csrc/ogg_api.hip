@@ -14,6 +14,14 @@ namespace ogg {
 
 static thread_local char g_err[512] = "";
 
+bool cap_symmetry(int requested) {
+    if (requested == OGG_SYM_MIRROR) return true;
+    if (requested == OGG_SYM_NONE) return false;
+    const char* e = getenv("OGG_CAP_SYMMETRY");   // OGG_SYM_DEFAULT
+    if (!e) return true;
+    return !(e[0] == '0' || e[0] == 'n' || e[0] == 'N');
+}
+
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -184,7 +192,7 @@ const char* ogg_last_error(void) { return ogg::g_err; }
 #define OGG_STR2(x) #x
 #define OGG_STR(x) OGG_STR2(x)
 const char* ogg_version(void) {
-    return "ogg_hip 0.4 (gfx950; libm restatements read from ROCm 7.2.0 ocml, built with HIP " OGG_STR(HIP_VERSION_MAJOR) "." OGG_STR(HIP_VERSION_MINOR) "." OGG_STR(
+    return "ogg_hip 0.5 (gfx950; cap columns mirrored by default, OGG_SYM_*; libm restatements read from ROCm 7.2.0 ocml, built with HIP " OGG_STR(HIP_VERSION_MAJOR) "." OGG_STR(HIP_VERSION_MINOR) "." OGG_STR(
         HIP_VERSION_PATCH) ") src " OGG_SRC_HASH;
 }
 // sizeof of the descriptor structs of the ABI (0: ogg_latlon_band, 1: ogg_bipolar_band), so that a binding can check its layout
@@ -345,8 +353,8 @@ int ogg_bipolar_projection(long n, const double* lamg, const double* phig, doubl
     return OGG_DOWNLOAD(h_j_inv, d_hj, n);
 }
 
-int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis, double* h_i_inv,
-                         double* h_j_inv) {
+int ogg_bipolar_cap_mesh_sym(long Ni, long Nj, double lat0_bp, double lon_bp, int symmetry, double* lams, double* phis, double* h_i_inv,
+                             double* h_j_inv) {
     OGG_REQUIRE(Ni > 0 && Nj > 0 && lams && phis, OGG_EARG, "ogg_bipolar_cap_mesh: bad argument");
     const long n = (Nj + 1) * (Ni + 1);
     DevScratch s;
@@ -355,7 +363,7 @@ int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double
     OGG_TRY(s.alloc(&d_ps, n));
     if (h_i_inv) OGG_TRY(s.alloc(&d_hi, (Nj + 1) * Ni));
     if (h_j_inv) OGG_TRY(s.alloc(&d_hj, Nj * (Ni + 1)));
-    OGG_TRY(ogg_bipolar_cap_mesh_dev(Ni, Nj, lat0_bp, lon_bp, 0, Nj + 1, d_ls, d_ps, d_hi, d_hj, s.stream()));
+    OGG_TRY(ogg_bipolar_cap_mesh_angle_sym_dev(Ni, Nj, lat0_bp, lon_bp, 0, Nj + 1, symmetry, d_ls, d_ps, d_hi, d_hj, nullptr, s.stream()));
     OGG_TRY(OGG_DOWNLOAD(lams, d_ls, n));
     OGG_TRY(OGG_DOWNLOAD(phis, d_ps, n));
     if (h_i_inv) OGG_TRY(OGG_DOWNLOAD(h_i_inv, d_hi, (Nj + 1) * Ni));
@@ -363,8 +371,13 @@ int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double
     return OGG_OK;
 }
 
-int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re, double* dxq,
-                                 double* dyq, double* daq) {
+int ogg_bipolar_cap_mesh(long Ni, long Nj, double lat0_bp, double lon_bp, double* lams, double* phis, double* h_i_inv,
+                         double* h_j_inv) {
+    return ogg_bipolar_cap_mesh_sym(Ni, Nj, lat0_bp, lon_bp, OGG_SYM_DEFAULT, lams, phis, h_i_inv, h_j_inv);
+}
+
+int ogg_bipolar_cap_metrics_quad_sym(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re, int symmetry,
+                                     double* dxq, double* dyq, double* daq) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     OGG_REQUIRE(nx > 0 && ny > 0 && dxq && dyq && daq, OGG_EARG, "ogg_bipolar_cap_metrics_quad: bad argument");
     DevScratch s;
@@ -372,10 +385,16 @@ int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, do
     OGG_TRY(s.alloc(&d_dx, (ny + 1) * nx));
     OGG_TRY(s.alloc(&d_dy, ny * (nx + 1)));
     OGG_TRY(s.alloc(&d_da, ny * nx));
-    OGG_TRY(ogg_bipolar_cap_metrics_quad_dev(order, nx, ny, lat0_bp, lon_bp, rp, Re, 0, ny + 1, ny, d_dx, d_dy, d_da, s.stream()));
+    OGG_TRY(ogg_bipolar_cap_metrics_quad_sym_ws_dev(order, nx, ny, lat0_bp, lon_bp, rp, Re, 0, ny + 1, ny, symmetry, d_dx, d_dy, d_da, nullptr, 0,
+                                                    s.stream()));
     OGG_TRY(OGG_DOWNLOAD(dxq, d_dx, (ny + 1) * nx));
     OGG_TRY(OGG_DOWNLOAD(dyq, d_dy, ny * (nx + 1)));
     return OGG_DOWNLOAD(daq, d_da, ny * nx);
+}
+
+int ogg_bipolar_cap_metrics_quad(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re, double* dxq,
+                                 double* dyq, double* daq) {
+    return ogg_bipolar_cap_metrics_quad_sym(order, nx, ny, lat0_bp, lon_bp, rp, Re, OGG_SYM_DEFAULT, dxq, dyq, daq);
 }
 
 // ---- displaced pole cap ------------------------------------------------------------------------------------
@@ -408,8 +427,8 @@ int ogg_displaced_pole_numerical_h(long n_i, const double* i, long n_j, const do
     return OGG_OK;
 }
 
-int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
-                                         double Re, double* dxq, double* dyq, double* daq) {
+int ogg_displaced_pole_metrics_quad_form_sym(int arc_form, int symmetry, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                             double r_dp, double Re, double* dxq, double* dyq, double* daq) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
     OGG_REQUIRE(nx > 0 && ny > 0 && dxq && dyq && daq, OGG_EARG, "ogg_displaced_pole_metrics_quad: bad argument");
@@ -420,7 +439,7 @@ int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long 
     OGG_TRY(s.alloc(&d_dy, ny * (nx + 1)));
     OGG_TRY(s.alloc(&d_da, ny * nx));
     OGG_TRY(s.alloc(&d_ws, (ws_bytes + 7) / 8));
-    OGG_TRY(ogg_displaced_pole_metrics_quad_form_ws_dev(arc_form, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, 0, ny + 1, ny, d_dx, d_dy,
+    OGG_TRY(ogg_displaced_pole_metrics_quad_form_sym_ws_dev(arc_form, symmetry, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, 0, ny + 1, ny, d_dx, d_dy,
                                                         d_da, d_ws, ws_bytes, s.stream()));
     OGG_TRY(OGG_DOWNLOAD(dxq, d_dx, (ny + 1) * nx));
     OGG_TRY(OGG_DOWNLOAD(dyq, d_dy, ny * (nx + 1)));
@@ -429,6 +448,11 @@ int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long 
     OGG_TRY(ogg_workspace_error_flag_dev(d_ws, &flag, s.stream()));
     OGG_REQUIRE(flag == 0, OGG_EHIP, "ogg_displaced_pole_metrics_quad: a look-back wait timed out (flag %d)", flag);
     return OGG_OK;
+}
+
+int ogg_displaced_pole_metrics_quad_form(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,
+                                         double Re, double* dxq, double* dyq, double* daq) {
+    return ogg_displaced_pole_metrics_quad_form_sym(arc_form, OGG_SYM_DEFAULT, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, dxq, dyq, daq);
 }
 
 int ogg_displaced_pole_metrics_quad(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp, double Re,

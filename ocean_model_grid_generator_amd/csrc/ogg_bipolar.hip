@@ -72,20 +72,25 @@ int ogg_bipolar_projection_dev(long n, const double* lamg, const double* phig, d
     return OGG_OK;
 }
 
-int ogg_bipolar_cap_mesh_angle_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
-                                   double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream) {
+int ogg_bipolar_cap_mesh_angle_sym_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, int symmetry, double* lams,
+                                       double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream) {
     OGG_REQUIRE(Ni > 0 && Nj > 0 && j0 >= 0 && nrows >= 0 && j0 + nrows <= Nj + 1, OGG_ESHAPE,
                 "ogg_bipolar_cap_mesh: rows %ld..%ld outside 0..%ld", j0, j0 + nrows, Nj);
     OGG_REQUIRE(lams && phis, OGG_EARG, "ogg_bipolar_cap_mesh: null output");
     if (nrows == 0) return OGG_OK;
-    MeshParams m{Ni, Nj, lat0_bp, lon_bp, j0, nrows, lams, phis, h_i_inv, h_j_inv, angle_dx, MESH_ROWS};
-    const dim3 grid = mesh_grid(m);
+    MeshParams m{Ni, Nj, lat0_bp, lon_bp, j0, nrows, lams, phis, h_i_inv, h_j_inv, angle_dx, MESH_ROWS, {}};
+    const dim3 grid = mesh_grid(m, ogg::cap_symmetry(symmetry) ? 1 : 0);
     if (h_i_inv || h_j_inv)
         bipolar_mesh_kernel<true><<<grid, 64 * MESH_WAVES, 0, ogg::as_stream(stream)>>>(m);
     else
         bipolar_mesh_kernel<false><<<grid, 64 * MESH_WAVES, 0, ogg::as_stream(stream)>>>(m);
     OGG_LAUNCH_CHECK();
     return OGG_OK;
+}
+
+int ogg_bipolar_cap_mesh_angle_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
+                                   double* phis, double* h_i_inv, double* h_j_inv, double* angle_dx, void* stream) {
+    return ogg_bipolar_cap_mesh_angle_sym_dev(Ni, Nj, lat0_bp, lon_bp, j0, nrows, OGG_SYM_DEFAULT, lams, phis, h_i_inv, h_j_inv, angle_dx, stream);
 }
 
 int ogg_bipolar_cap_mesh_dev(long Ni, long Nj, double lat0_bp, double lon_bp, long j0, long nrows, double* lams,
@@ -114,9 +119,9 @@ long ogg_bipolar_quad_workspace_bytes(int order, long nx, long ny) {
     }
 }
 
-int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
-                                        long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
-                                        void* workspace, long workspace_bytes, void* stream) {
+int ogg_bipolar_cap_metrics_quad_sym_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                            long j0, long n_dx_rows, long n_cell_rows, int symmetry, double* dxq, double* dyq, double* daq,
+                                            void* workspace, long workspace_bytes, void* stream) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     OGG_REQUIRE(nx > 0 && ny > 0 && dxq && (n_cell_rows <= 0 || (dyq && daq)), OGG_EARG, "ogg_bipolar_cap_metrics_quad: bad argument");
     OGG_REQUIRE(j0 >= 0 && n_cell_rows >= 0 && j0 + n_cell_rows <= ny &&
@@ -131,12 +136,20 @@ int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0
     p.nx = nx, p.ny = ny, p.lat0_bp = lat0_bp, p.lon_bp = lon_bp, p.rp = rp, p.Re = Re, p.j0 = j0;
     p.dxq = dxq, p.dyq = dyq, p.daq = daq, p.q = make_nodes(order);
     hipStream_t s = ogg::as_stream(stream);
+    const int sym = ogg::cap_symmetry(symmetry) ? 1 : 0;
     switch (order) {
-        case 2: return launch_quad<2>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
-        case 3: return launch_quad<3>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
-        case 4: return launch_quad<4>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
-        default: return launch_quad<5>(p, n_dx_rows, n_cell_rows, gap, workspace, workspace_bytes, s);
+        case 2: return launch_quad<2>(p, n_dx_rows, n_cell_rows, gap, sym, workspace, workspace_bytes, s);
+        case 3: return launch_quad<3>(p, n_dx_rows, n_cell_rows, gap, sym, workspace, workspace_bytes, s);
+        case 4: return launch_quad<4>(p, n_dx_rows, n_cell_rows, gap, sym, workspace, workspace_bytes, s);
+        default: return launch_quad<5>(p, n_dx_rows, n_cell_rows, gap, sym, workspace, workspace_bytes, s);
     }
+}
+
+int ogg_bipolar_cap_metrics_quad_ws_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,
+                                        long j0, long n_dx_rows, long n_cell_rows, double* dxq, double* dyq, double* daq,
+                                        void* workspace, long workspace_bytes, void* stream) {
+    return ogg_bipolar_cap_metrics_quad_sym_ws_dev(order, nx, ny, lat0_bp, lon_bp, rp, Re, j0, n_dx_rows, n_cell_rows, OGG_SYM_DEFAULT, dxq,
+                                                   dyq, daq, workspace, workspace_bytes, stream);
 }
 
 int ogg_bipolar_cap_metrics_quad_dev(int order, long nx, long ny, double lat0_bp, double lon_bp, double rp, double Re,

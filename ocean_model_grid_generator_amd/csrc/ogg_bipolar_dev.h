@@ -191,11 +191,15 @@ OGG_DEV double asin_unit(double x) {
     return v;
 }
 
-// lams of OGG:50-64
-OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double sqrt_rden, double lamg, double lon_bp) {   // sqrt_rden: sqrt(rden), IEEE
+// lamc of OGG:50-53 (degrees, before the root selection of OGG:58-63)
+OGG_DEV double bp_lamc(const BpRow& r, const BpCol& c, double sqrt_rden) {   // sqrt_rden: sqrt(rden), IEEE
     double B = c.sinla * sqrt_rden;
     if (fabs(r.beta2_inv) > kHuge) B = 0.0;
-    double lamc = div_pi180(asin_unit(B));   // B in [0, 1]
+    return div_pi180(asin_unit(B));   // B in [0, 1]
+}
+
+// lams of OGG:58-64 from lamc
+OGG_DEV double bp_lams_select(double lamc, double lamg, double lon_bp) {
     const double dl = lamg - lon_bp;
     if ((dl > 90) && (dl <= 180)) lamc = 180 - lamc;
     if ((dl > 180) && (dl <= 270)) lamc = 180 + lamc;
@@ -203,6 +207,11 @@ OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double sqrt_rden, double 
     if (dl == 90) lamc = 90;
     if (dl == 270) lamc = 270;
     return lamc + lon_bp;
+}
+
+// lams of OGG:50-64
+OGG_DEV double bp_lams(const BpRow& r, const BpCol& c, double sqrt_rden, double lamg, double lon_bp) {
+    return bp_lams_select(bp_lamc(r, c, sqrt_rden), lamg, lon_bp);
 }
 
 // ---- element-wise projection on arbitrary inputs ---------------------------------------------------------
@@ -274,12 +283,49 @@ constexpr int MESH_OUT = 62;   // output columns per wave
 constexpr int MESH_ROWS = 8;       // rows per workgroup: the default (OGG_MESH_ROWS: 1 .. MESH_ROWS_MAX)
 constexpr int MESH_ROWS_MAX = 32;  // LDS entries for the row factors
 
+// The columns a mesh launch evaluates: up to four runs of consecutive columns, each a whole number of wave blocks (MESH_OUT columns).
+// Without symmetry one run, 0 .. Ni.  With it (the same symmetry as QuadCols, for lams, phis and angle_dx: with lamc the longitude
+// before the root selection of OGG:58-63, the images of column i are (180 - lamc) + lon_bp at Ni/2 - i, (180 + lamc) + lon_bp at
+// Ni/2 + i, (360 - lamc) + lon_bp at Ni - i -- the reference's own last operations on ITS lamc --, phis is the same, angle_dx changes
+// sign under a mirror image and not under the half turn) the columns zf < i < Ni/4 - zm of run 0 = [0, Ni/4 + zm] also write their
+// three images; evaluated at their own columns: [0, zf] and its images (the end columns i = 0, Ni take one-sided differences in
+// angle_x, OGG:726-727, their images Ni/2 -+ 0 do not), and zm columns either side of the pole meridians Ni/4, 3Ni/4, where asin(B),
+// B -> 1, amplifies the last-bit differences between the reference's own columns to 4.9e-12 degrees in x one column from the meridian
+// (1/8 degree; 7.2e-12 at 1/16), falling as 1 / distance: 3.4e-13 two degrees away, which is where the zone ends (mesh_cols).
+struct MeshCols {
+    long lo[4], hi[4];   // columns [lo, hi] of run r
+    long w_end[4];       // wave blocks of runs 0 .. r
+    long zf, m_hi;       // images for zf < i < m_hi
+    int sym;
+};
+
+struct MeshLane {
+    long i;          // this lane's column (halo lanes beyond the row ends are clamped)
+    bool active;     // the wave block exists (wave-uniform)
+    bool out;        // writes column i ...
+    bool img;        // ... and its three images Ni/2 - i, Ni/2 + i, Ni - i
+};
+
+OGG_HD MeshLane mesh_lane(const MeshCols& mc, long Ni, long w, int lane, int out_cols) {   // w: wave block of the launch's column space
+    MeshLane m{};
+    m.active = w < mc.w_end[3];
+    const int run = (w < mc.w_end[0]) ? 0 : ((w < mc.w_end[1]) ? 1 : ((w < mc.w_end[2]) ? 2 : 3));
+    const long w0 = (run == 0) ? 0 : mc.w_end[run - 1];
+    const long col0 = mc.lo[run] + (w - w0) * out_cols;   // first output column of this wave
+    long i = col0 - 1 + lane;
+    m.out = m.active && (lane >= 1) && (lane <= out_cols) && (i <= mc.hi[run]);
+    m.i = i < 0 ? 0 : (i > Ni ? Ni : i);
+    m.img = mc.sym && run == 0 && m.out && m.i > mc.zf && m.i < mc.m_hi;
+    return m;
+}
+
 struct MeshParams {
     long Ni, Nj;
     double lat0_bp, lon_bp;
     long j0, nrows;
     double *lams, *phis, *hi, *hj, *angle;
     int rows_per_wg;   // 1..MESH_ROWS_MAX
+    MeshCols cols;
 };
 
 // workgroup (bx, by) of the mesh grid; s_row: MESH_ROWS_MAX entries of LDS.  WITH_H = false leaves the scale factors out of the
@@ -303,11 +349,11 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
         s_row[tid] = bp_row(phig, rp);
     }
     __syncthreads();
-    const long col0 = (bx * MESH_WAVES + wave) * MESH_OUT;  // first output column of this wave
-    if (col0 > Ni) return;                                                // wave-uniform
-    long i = col0 - 1 + lane;
-    i = i < 0 ? 0 : (i > Ni ? Ni : i);                                    // halo lanes beyond the row ends are clamped
-    const bool out = (lane >= 1) && (lane <= MESH_OUT) && (col0 - 1 + lane <= Ni);
+    const MeshLane ml = mesh_lane(m.cols, Ni, bx * MESH_WAVES + wave, lane, MESH_OUT);
+    if (!ml.active) return;                                                // wave-uniform
+    const long i = ml.i;
+    const bool out = ml.out, img = ml.img;                                 // img: this column also writes its three images
+    const long h2 = Ni / 2;
     const double lamg = lon_bp + ((double)i * 360.0) / (double)Ni;                     // OGG:113
     const BpCol c = bp_col(lamg, lon_bp);
     const long ni1 = Ni + 1;
@@ -317,21 +363,36 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
         // OGG:47, and the square root of OGG:50: IEEE division and root -- the same bits -- without the scaling and special-case steps
         // that 1 <= 1 + a b <= 1e33 does not need (a in [0, 1]; b = tan^2 of a latitude that is at most 90 degrees ROUNDED: <= 2.7e32)
         const double rden = rcp_ieee_normal(1.0 + c.alpha2 * row.beta2_inv);
-        const double lam = bp_lams(row, c, sqrt_ieee_normal(rden), lamg, lon_bp);
+        const double lamc = bp_lamc(row, c, sqrt_ieee_normal(rden));
+        const double lam = bp_lams_select(lamc, lamg, lon_bp);
         const double A = c.sinla * row.sphig;
         const double m1 = 1 - A, p1 = 1 + A;
         const double t = (m1 > 0.0) ? m1 * rsqrt_c3(m1 * p1) : 0.0;                    // sqrt((1-A)/(1+A)) == tan(acos(A)/2), OGG:69-70
         const double u = rp * t;
         const double phi = 90 - div_pi180(2 * atan_cap(u));
+        double* __restrict__ rl = lams + jl * ni1;
+        double* __restrict__ rph = phis + jl * ni1;
         if (out) {
-            lams[jl * ni1 + i] = lam;
-            phis[jl * ni1 + i] = phi;
+            rl[i] = lam;
+            rph[i] = phi;
+        }
+        if (img) {                                                                     // OGG:58-64 at the image columns, from this lamc
+            rl[h2 - i] = (180 - lamc) + lon_bp, rl[h2 + i] = (180 + lamc) + lon_bp, rl[Ni - i] = (360 - lamc) + lon_bp;
+            rph[h2 - i] = phi, rph[h2 + i] = phi, rph[Ni - i] = phi;
         }
         if (WITH_H && (hi || hj)) {
             double ps, h_i, h_j, rd;
             bp_point(row, c, rp, ps, h_i, h_j, rd);
-            if (out && hi && i < Ni) hi[jl * Ni + i] = h_i * 2 * kPi / (double)Ni;                    // OGG:119
-            if (out && hj && j < Nj) hj[jl * ni1 + i] = h_j * kPi180 * (90 - lat0_bp) / (double)Nj;   // OGG:120
+            if (out && hi && i < Ni) {
+                const double v = h_i * 2 * kPi / (double)Ni;                                          // OGG:119
+                hi[jl * Ni + i] = v;
+                if (img) hi[jl * Ni + h2 - i] = v, hi[jl * Ni + h2 + i] = v, hi[jl * Ni + Ni - i] = v;
+            }
+            if (out && hj && j < Nj) {
+                const double v = h_j * kPi180 * (90 - lat0_bp) / (double)Nj;                          // OGG:120
+                hj[jl * ni1 + i] = v;
+                if (img) hj[jl * ni1 + h2 - i] = v, hj[jl * ni1 + h2 + i] = v, hj[jl * ni1 + Ni - i] = v;
+            }
         }
         if (angle) {                                                                   // OGG:725-728
             const double xl = wave_prev(lam), xr = wave_next(lam);
@@ -346,7 +407,10 @@ OGG_DEV void bipolar_mesh_body(const MeshParams& m, BpRow* s_row, long bx, long 
                 a = atan2_angle(phi - yl, (lam - xl) * cy);
             else
                 a = atan2_angle(yr - yl, (xr - xl) * cy);
-            if (out) angle[jl * ni1 + i] = div_pi180(a);
+            a = div_pi180(a);
+            double* __restrict__ ra = angle + jl * ni1;
+            if (out) ra[i] = a;
+            if (img) ra[h2 - i] = -a, ra[h2 + i] = a, ra[Ni - i] = -a;
         }
     }
 }
@@ -357,10 +421,38 @@ __global__ __launch_bounds__(64 * MESH_WAVES) void bipolar_mesh_kernel(MeshParam
     bipolar_mesh_body<WITH_H>(m, s_row, blockIdx.x, blockIdx.y);
 }
 
-// sets m.rows_per_wg.  The column-only factors (sincos + two fmod) cost about as much as half a point, so a wave keeps
+constexpr double BP_SYM_MESH_MERIDIAN_DEG = 2.0;   // MeshCols: degrees of longitude either side of a pole meridian evaluated at their own columns
+constexpr long BP_SYM_MESH_FOLD_COLS = 2;          // ... and columns next to the fold lines i = 0, Ni/2, Ni
+
+inline MeshCols mesh_cols(long Ni, int symmetry) {
+    MeshCols c{};
+    auto blocks = [](long lo, long hi) { return (hi - lo + 1 + MESH_OUT - 1) / MESH_OUT; };
+    for (int r = 0; r < 4; ++r) c.lo[r] = 0, c.hi[r] = -1;
+    c.lo[0] = 0, c.hi[0] = Ni;
+    c.w_end[0] = c.w_end[1] = c.w_end[2] = c.w_end[3] = blocks(0, Ni);
+    c.zf = Ni, c.m_hi = 0, c.sym = 0;
+    if (!symmetry || Ni % 4 != 0) return c;
+    double deg = BP_SYM_MESH_MERIDIAN_DEG;
+    if (const char* e = getenv("OGG_BP_SYM_MESH_DEG")) deg = atof(e);
+    const long q = Ni / 4, zf = BP_SYM_MESH_FOLD_COLS;
+    long zm = (long)ceil(deg * (double)Ni / 360.0);
+    if (zm < 2) zm = 2;
+    if (zf + 1 >= q - zm) return c;   // nothing left to mirror
+    c.sym = 1, c.zf = zf, c.m_hi = q - zm;
+    c.lo[0] = 0, c.hi[0] = q + zm;
+    c.lo[1] = 2 * q - zf, c.hi[1] = 2 * q + zf;
+    c.lo[2] = 3 * q - zm, c.hi[2] = 3 * q + zm;
+    c.lo[3] = Ni - zf, c.hi[3] = Ni;
+    long w = 0;
+    for (int r = 0; r < 4; ++r) w += blocks(c.lo[r], c.hi[r]), c.w_end[r] = w;
+    return c;
+}
+
+// sets m.rows_per_wg and m.cols.  The column-only factors (sincos + two fmod) cost about as much as half a point, so a wave keeps
 // MESH_ROWS rows even when the band is small: fewer rows per workgroup measured slower down to 1/8 of the 1/8 degree cap.
-inline dim3 mesh_grid(MeshParams& m) {
-    const long n_waves = (m.Ni + 1 + MESH_OUT - 1) / MESH_OUT;
+inline dim3 mesh_grid(MeshParams& m, int symmetry) {
+    m.cols = mesh_cols(m.Ni, symmetry);
+    const long n_waves = m.cols.w_end[3];
     const long gx = (n_waves + MESH_WAVES - 1) / MESH_WAVES;
     long rpw = MESH_ROWS;
     if (const char* e = getenv("OGG_MESH_ROWS")) rpw = atol(e) < 1 ? 1 : (atol(e) > MESH_ROWS_MAX ? MESH_ROWS_MAX : atol(e));
@@ -395,11 +487,54 @@ struct QuadParams {
     double sx, sy, rp2p, rp2m, rp2x4, cdx, guard_kk;
 };
 
+// The columns a grid of strip workgroups walks, as ONE compact index space of up to three runs of consecutive cells, each closed by the
+// node column behind its last cell (a "closing" entry: it feeds dyq only).  Without symmetry there is one run, the cells 0 .. nx-1
+// closed by column nx.  With it (QuadCols::sym): the projection is mirror-symmetric about its two pole meridians (lattice columns
+// nx/4, 3nx/4) and about the fold lines (columns 0, nx/2) -- sinla and alpha2 (OGG:42-45) are functions of min(d, 360 - d) and of
+// sin / cos^2 of it --, so the cells [0, nx/4) determine the whole row: a lane that owns cell i >= z also writes its values to the
+// cells nx/2-1-i, nx/2+i, nx-1-i (dyq, on node columns: i > z to nx/2-i, nx/2+i, nx-i).  The reference evaluates every column with
+// its own roundings (lon_bp + i 360/Ni is rounded at magnitude 300 at one end of the row and at 60 at the other), and its own results
+// are mirror images of each other only to ~5.7e-14 degrees / (distance from the fold line): the z cells next to each fold line
+// (plan_quad: 6 degrees of longitude, where the reference's own asymmetry has fallen to 7e-15 relative in area, 3e-15 in dx, 5e-15 in
+// dy at 1/8 and 1/16 degree) are therefore evaluated at their own columns: run 1 = cells [nx/2-z, nx/2+z), run 2 =
+// [nx-z, nx), and the cells [0, z) of run 0 have no images.
+struct QuadCols {
+    long r1, r2, total;   // compact entries of run 0: [0, r1), run 1: [r1, r2), run 2: [r2, total); the last entry of a run is its closing column
+    long lo1, lo2;        // first cell of run 1, of run 2 (run 0 starts at cell 0)
+    long z;               // sym: cells [0, z) of run 0 (columns [0, z]) have no images
+    int sym;
+};
+
+// what lane `lane` of strip `strip` owns in the column space `cs`
+struct QuadLane {
+    long ci;          // its cell = its node column (the cell's left edge)
+    bool active;      // the strip exists (wave-uniform)
+    bool col_lane;    // writes dyq at node column ci ...
+    bool cell_lane;   // ... and dxq, daq of cell ci
+    bool img_cell;    // and the three mirror images of the cell: cells nx/2-1-ci, nx/2+ci, nx-1-ci
+    bool img_col;     // of the node column: columns nx/2-ci, nx/2+ci, nx-ci
+};
+
+OGG_HD QuadLane quad_lane(const QuadCols& cs, long strip, int lane, int cells_per_strip) {
+    QuadLane q{};
+    q.active = strip * cells_per_strip < cs.total;
+    const long ke = strip * cells_per_strip + lane;   // compact entry of this lane; the last lane of a wave: the first entry of the next strip
+    const long kk = ke < cs.total ? ke : cs.total - 1;
+    q.ci = kk < cs.r1 ? kk : (kk < cs.r2 ? cs.lo1 + (kk - cs.r1) : cs.lo2 + (kk - cs.r2));
+    const bool closing = (kk == cs.r1 - 1) || (kk == cs.r2 - 1) || (kk == cs.total - 1);
+    q.col_lane = q.active && (lane < cells_per_strip) && (ke < cs.total);
+    q.cell_lane = q.col_lane && !closing;
+    q.img_cell = cs.sym && q.cell_lane && kk < cs.r1 && q.ci >= cs.z;
+    q.img_col = cs.sym && q.col_lane && kk < cs.r1 && q.ci > cs.z;
+    return q;
+}
+
 struct QuadRange {     // the part of the band one grid of strip workgroups evaluates
     long row_begin;    // cell rows [row_begin, row_end)
     long row_end;
     long rows_per_chunk;  // cell rows one wave walks (its first lattice row is recomputed: 1/((N-1)*rows_per_chunk) extra)
-    unsigned gy;       // workgroups along the rows
+    unsigned gx, gy;   // workgroups along the columns (strips of cols / QS_WAVES), along the rows
+    QuadCols cols;
 };
 
 // row-only and column-only parts of the projection for every unique lattice row / column of the cap (OGG:126-127,
@@ -595,8 +730,9 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
     constexpr int M = N - 1;
     constexpr bool FAITHFUL = (MODE == QM_LITERAL);
     const int lane = threadIdx.x & 63;
-    if (strip * QS_CELLS >= p.nx) return;  // wave-uniform
-    const long ci = strip * QS_CELLS + lane;
+    const QuadLane ql = quad_lane(rg.cols, strip, lane, QS_CELLS);
+    if (!ql.active) return;  // wave-uniform
+    const long ci = ql.ci;
     const long n_cols_tab = M * p.nx + 1;
     BpCol col[M];
 #pragma unroll
@@ -605,7 +741,9 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         if (u > n_cols_tab - 1) u = n_cols_tab - 1;
         col[ii] = p.col_tab[u];
     }
-    const bool cell_lane = (lane < QS_CELLS) && (ci < p.nx);
+    const bool col_lane = ql.col_lane, cell_lane = ql.cell_lane;
+    const bool img_cell = (MODE == QM_FAST) && ql.img_cell, img_col = (MODE == QM_FAST) && ql.img_col;
+    const long h2 = p.nx / 2;
     double rp2p = p.rp2p;
     asm volatile("" : "+v"(rp2p));   // held in a vector register for the whole walk (else re-copied from its scalar register per point)
     RowEval<N, MODE> cur;
@@ -649,10 +787,13 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         }
         // cur now holds lattice row (c, N-1) == (c+1, 0): the bottom row of the next cell row
         const long out_r = c - p.j0;
-        if (ci == p.nx) p.dyq[out_r * (p.nx + 1) + p.nx] = quad_average_1d<N>(dyc) * p.Re;  // first node column of cell nx
+        if (col_lane) {
+            const double dyq = quad_average_1d<N>(dyc) * p.Re;                                // OGG:184,187
+            double* __restrict__ row = p.dyq + out_r * (p.nx + 1);
+            row[ci] = dyq;
+            if (img_col) row[h2 - ci] = dyq, row[h2 + ci] = dyq, row[p.nx - ci] = dyq;
+        }
         if (cell_lane) {
-            p.dxq[out_r * p.nx + ci] = dxq;
-            p.dyq[out_r * (p.nx + 1) + ci] = quad_average_1d<N>(dyc) * p.Re;                  // OGG:184,187
             double da;
             if (N == 2) {
                 const double d = 1.0 / 2.0;
@@ -665,7 +806,15 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
                 const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
                 da = d * d * ysum;
             }
-            p.daq[out_r * p.nx + ci] = da * p.Re * p.Re;                                      // OGG:185
+            da = da * p.Re * p.Re;                                                            // OGG:185
+            double* __restrict__ rdx = p.dxq + out_r * p.nx;
+            double* __restrict__ rda = p.daq + out_r * p.nx;
+            rdx[ci] = dxq;
+            rda[ci] = da;
+            if (img_cell) {
+                rdx[h2 - 1 - ci] = dxq, rdx[h2 + ci] = dxq, rdx[p.nx - 1 - ci] = dxq;
+                rda[h2 - 1 - ci] = da, rda[h2 + ci] = da, rda[p.nx - 1 - ci] = da;
+            }
             if (MODE == QM_GUARD && guarded) p.fix_list[atomicAdd(p.fix_count, 1u)] = (unsigned)(out_r * p.nx + ci);
         }
     }
@@ -798,14 +947,35 @@ size_t quad_workspace_bytes(long nx, long ny, long n_cell_rows) {
 // band owns the j = ny row; shared by the function-level entry point and by the fused pass (ogg_pass.hip).
 struct QuadPlan {
     QuadParams p;
-    unsigned gx;                 // strip workgroups along the columns
     bool has_fast, has_guard, has_top;   // has_top: the band owns the j = ny row of dxq (evaluated with the tables)
     QuadRange fast, guard;
     double* top_buf;             // nx doubles at the end of the workspace (QuadParams::top_src)
 };
 
+constexpr double BP_SYM_FOLD_DEG = 6.0;   // QuadCols: degrees of longitude next to a fold line that are evaluated at their own columns
+
+// the compact column space of a range of cell rows (QuadCols).  symmetry: the caller asks for mirrored columns; taken when nx is a multiple of
+// 4 (the pole meridians are node columns) and the literal zones leave something to mirror
+inline QuadCols quad_cols(long nx, int symmetry) {
+    QuadCols c{};
+    c.r1 = c.r2 = c.total = nx + 1;
+    c.lo1 = c.lo2 = 0, c.z = nx, c.sym = 0;
+    if (!symmetry || nx % 4 != 0) return c;
+    double deg = BP_SYM_FOLD_DEG;
+    if (const char* e = getenv("OGG_BP_SYM_FOLD_DEG")) deg = atof(e);
+    const long q = nx / 4;
+    long z = (long)ceil(deg * (double)nx / 360.0);
+    if (z < 1) z = 1;
+    if (2 * z > q) return c;
+    c.sym = 1, c.z = z;
+    c.r1 = q + 1;                  // cells [0, q) + column q
+    c.lo1 = 2 * q - z, c.r2 = c.r1 + 2 * z + 1;   // cells [nx/2 - z, nx/2 + z) + column nx/2 + z
+    c.lo2 = nx - z, c.total = c.r2 + z + 1;       // cells [nx - z, nx) + column nx
+    return c;
+}
+
 template <int N>
-int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, void* ws, long ws_bytes, QuadPlan& out) {
+int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, int symmetry, void* ws, long ws_bytes, QuadPlan& out) {
     constexpr int M = N - 1;
     const long n_rows = M * p.ny + 2, n_cols = M * p.nx + 1;
     const size_t need = quad_workspace_bytes<N>(p.nx, p.ny, n_cell_rows);
@@ -828,8 +998,6 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     p.cdx = (2 * p.rp) * p.sx;
     p.guard_kk = guard_k * p.rp2x4;
     out.p = p;
-    const long n_strips = (p.nx + QS_CELLS - 1) / QS_CELLS;
-    out.gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);
     // A point can only be guarded where cos^2(phis) < 1/K and phis never exceeds the grid latitude of its lattice row, so the
     // cell rows whose top edge lies below acos(2/sqrt(K)) (a factor 4 of margin on cos^2) run without the guard.
     long jg = 0;  // first cell row that carries the guard
@@ -840,10 +1008,13 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     if (jg < 0) jg = 0;
     if (jg > p.ny) jg = p.ny;
     const long lo = p.j0, hi = p.j0 + n_cell_rows;
-    auto range = [&](long b, long e) {
+    auto range = [&](long b, long e, int sym) {
         QuadRange r{};
         r.row_begin = b;
         r.row_end = e;
+        r.cols = quad_cols(p.nx, sym);
+        const long n_strips = (r.cols.total + QS_CELLS - 1) / QS_CELLS;
+        r.gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);
         // enough waves to fill 1024 SIMDs (x 3 wave slots) more than once, without recomputing more than 1-2 % of the lattice rows (8192: +1.5 %)
         long target = 4096;
         if (const char* ev = getenv("OGG_QUAD_TARGET_WAVES")) target = atol(ev) > 0 ? atol(ev) : target;
@@ -855,8 +1026,10 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, vo
     out.has_fast = lo < hi && lo < jg;
     out.has_guard = lo < hi && hi > jg;
     out.has_top = n_dx_rows > n_cell_rows;
-    if (out.has_fast) out.fast = range(lo, hi < jg ? hi : jg);
-    if (out.has_guard) out.guard = range(lo > jg ? lo : jg, hi);
+    // (the rows that carry the guard -- above 88.2 degrees for K = 4000 -- are evaluated at every column: the reference's own asymmetry
+    // reaches 4.6e-12 relative in the cells next to the pole points)
+    if (out.has_fast) out.fast = range(lo, hi < jg ? hi : jg, symmetry);
+    if (out.has_guard) out.guard = range(lo > jg ? lo : jg, hi, 0);
     return OGG_OK;
 }
 
@@ -872,7 +1045,7 @@ int launch_quad_tail(const QuadPlan& q, hipStream_t s) {
 }
 
 template <int N>
-int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
+int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, int symmetry, void* ext_ws, long ext_ws_bytes, hipStream_t s) {
     // workspace (row/column tables, fix-up counter and list): the caller's (graph-capturable: no allocation at all), or from
     // the stream-ordered allocator (no host synchronisation, safe with concurrent streams)
     const size_t need = quad_workspace_bytes<N>(p.nx, p.ny, n_cell_rows);
@@ -884,15 +1057,15 @@ int launch_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, 
         ws_bytes = (long)need;
     }
     QuadPlan q;
-    if (int e = plan_quad<N>(p, n_dx_rows, n_cell_rows, guard_k, ws, ws_bytes, q)) return e;
+    if (int e = plan_quad<N>(p, n_dx_rows, n_cell_rows, guard_k, symmetry, ws, ws_bytes, q)) return e;
     bipolar_tables_kernel<N><<<tables_blocks<N>(q.p), 256, 0, s>>>(q.p);
     OGG_LAUNCH_CHECK();
     if (q.has_fast) {
-        bipolar_quad_kernel<N, QM_FAST><<<dim3(q.gx, q.fast.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.fast);
+        bipolar_quad_kernel<N, QM_FAST><<<dim3(q.fast.gx, q.fast.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.fast);
         OGG_LAUNCH_CHECK();
     }
     if (q.has_guard) {
-        bipolar_quad_kernel<N, QM_GUARD><<<dim3(q.gx, q.guard.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.guard);
+        bipolar_quad_kernel<N, QM_GUARD><<<dim3(q.guard.gx, q.guard.gy), 64 * QS_WAVES, 0, s>>>(q.p, q.guard);
         OGG_LAUNCH_CHECK();
     }
     return launch_quad_tail<N>(q, s);

@@ -13,6 +13,9 @@ int set_error(int code, const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// OGG_SYM_DEFAULT / OGG_SYM_MIRROR / OGG_SYM_NONE of a caller -> mirror the caps' columns or not (include/ogg_hip.h)
+bool cap_symmetry(int requested);
+
 // Scratch from the stream-ordered allocator (no host synchronisation), returned to it on EVERY exit path of the call.
 class AsyncScratch {
    public:

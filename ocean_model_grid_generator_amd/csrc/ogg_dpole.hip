@@ -510,9 +510,10 @@ int ogg_workspace_error_flag_dev(const void* workspace, int* flag, void* stream)
     return OGG_OK;
 }
 
-int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
-                                                double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
-                                                double* dyq, double* daq, void* workspace, long workspace_bytes, void* stream) {
+int ogg_displaced_pole_metrics_quad_form_sym_ws_dev(int arc_form, int symmetry, int order, long nx, long ny, double lon0, double lat0,
+                                                    double lon_dp, double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows,
+                                                    double* dxq, double* dyq, double* daq, void* workspace, long workspace_bytes,
+                                                    void* stream) {
     OGG_REQUIRE(order >= 2 && order <= 5, OGG_EORDER, "Uncoded order");
     // the quadrature order is forwarded as the finite-difference order (OGG:583-584): 3 and 5 are "not coded" there
     OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
@@ -534,7 +535,7 @@ int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx
     }
     DpQuadParams p{};
     if (int e = plan_dquad(arc_form, order, DpGeom{nx, ny, lon0, lat0, lon_dp, r_dp}, Re, j0, n_dx_rows, n_cell_rows, dxq, dyq, daq, ws,
-                           ws_bytes, ogg::quad_nodes_host(order), p))
+                           ws_bytes, ogg::quad_nodes_host(order), p, ogg::cap_symmetry(symmetry) ? 1 : 0))
         return e;
     const unsigned nwg = (unsigned)(p.gx * p.n_chunks);
     const char* walk = getenv("OGG_DQ_WALK");
@@ -559,6 +560,13 @@ int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx
     OGG_LAUNCH_CHECK();
     if (!workspace && arc_form == OGG_DP_ARC_LITERAL) return check_own_workspace(ws, s, "ogg_displaced_pole_metrics_quad");
     return OGG_OK;
+}
+
+int ogg_displaced_pole_metrics_quad_form_ws_dev(int arc_form, int order, long nx, long ny, double lon0, double lat0, double lon_dp,
+                                                double r_dp, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
+                                                double* dyq, double* daq, void* workspace, long workspace_bytes, void* stream) {
+    return ogg_displaced_pole_metrics_quad_form_sym_ws_dev(arc_form, OGG_SYM_DEFAULT, order, nx, ny, lon0, lat0, lon_dp, r_dp, Re, j0,
+                                                           n_dx_rows, n_cell_rows, dxq, dyq, daq, workspace, workspace_bytes, stream);
 }
 
 int ogg_displaced_pole_metrics_quad_ws_dev(int order, long nx, long ny, double lon0, double lat0, double lon_dp, double r_dp,

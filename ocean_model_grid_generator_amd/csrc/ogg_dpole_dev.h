@@ -365,6 +365,16 @@ struct DpQuadParams {
     long n_rows, n_cols;         // unique lattice rows of the band (M n_cell_rows + 1), lattice columns (M nx + 1)
     long rows_per_chunk;         // cell rows one wave walks (its first lattice row is the last one of the chunk below, recomputed)
     long n_chunks, n_strips, gx; // gx = strip workgroups per chunk
+    // The lattice columns the strips walk: all of them, 0 .. n_cols - 1, or (sym, chord form only) the half that determines the rest.
+    // The map of OGG:447-467 is mirror-symmetric about the meridian through lon_dp: when that meridian is a node column,
+    // i_c = (lon_dp - lon0) ni / 360 an integer, and ni is even, the cells [c_first, c_first + ni/2) with c_first = i_c or i_c - ni/2
+    // (the one that does not wrap) are evaluated and cell c also writes its values to cell (2 c_first - 1 - c) mod ni, node column c
+    // (dyq) to column (2 c_first - c) mod ni; column ni is the twin of column 0 (the same meridian, lon0 + 360).  The reference's own
+    // results are mirror images of each other to the level of its own finite-difference noise (1e-10 at ni = 720, 6e-10 at 2880,
+    // uniformly in i: the oracle), which is also how far it is from the exact value of its formula.
+    long u_first, n_src_cols;    // first lattice column of the strips, number of lattice columns they cover (M c_first, M ni / 2 + 1)
+    long c_first, c_end;         // cells [c_first, c_end) write dxq / daq; node columns [c_first, c_end] write dyq
+    int sym;
     QuadNodes q;
     const double* row_tab;       // [NV][n_rows]: gnomonic radius of the row variants (base, +eps, -eps, +2eps, -2eps, ...)
     const double* col_tab;       // [NV][2][n_cols]: e' of the column variants
@@ -372,6 +382,31 @@ struct DpQuadParams {
     unsigned* ticket;            // work counter; ticket[1] is the error flag
     double *dxq, *dyq, *daq;
 };
+
+// what lane `lane` of strip `strip` owns: its lattice column, and what it writes
+struct DqLane {
+    long uc, ci;            // lattice column (clamped to the last one), its cell
+    bool active;            // the strip exists (wave-uniform)
+    bool valid, cell_start;
+    bool out_lane;          // writes dxq, dyq, daq of cell ci
+    bool dy_edge;           // the node column behind the last cell: dyq only
+    long cm, pm;            // sym: mirror image of the cell, of the node column (a column that lands on 0 also writes its twin ni)
+};
+
+OGG_HD DqLane dq_lane(const DpQuadParams& p, int M, long strip, int lane, int cols_per_strip) {
+    DqLane q{};
+    const long u0 = strip * cols_per_strip;
+    q.active = u0 < p.n_src_cols - 1;            // else nothing but another strip's halo column (n_src_cols >= 2)
+    q.valid = u0 + lane < p.n_src_cols;
+    q.uc = p.u_first + (q.valid ? u0 + lane : p.n_src_cols - 1);
+    q.ci = q.uc / M;
+    q.cell_start = q.valid && (q.uc % M == 0);
+    q.out_lane = q.active && q.cell_start && q.ci < p.c_end && lane <= cols_per_strip - M;
+    q.dy_edge = q.active && q.cell_start && q.ci == p.c_end;
+    long cm = 2 * p.c_first - 1 - q.ci, pm = 2 * p.c_first - q.ci;
+    q.cm = cm < 0 ? cm + p.g.ni : cm, q.pm = pm < 0 ? pm + p.g.ni : pm;
+    return q;
+}
 
 // Row / column tables of one call and the reset of its look-back words; n_words = 0 for the chord form.
 template <int N>
@@ -440,7 +475,7 @@ inline size_t dq_workspace_bytes(int order, long nx, long n_cell_rows) {
 }
 
 inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long j0, long n_dx_rows, long n_cell_rows, double* dxq,
-                      double* dyq, double* daq, void* ws, long ws_bytes, const QuadNodes& q, DpQuadParams& p) {
+                      double* dyq, double* daq, void* ws, long ws_bytes, const QuadNodes& q, DpQuadParams& p, int symmetry = 0) {
     const long M = order - 1, NV = order + 1;
     const size_t need = dq_workspace_bytes(order, g.ni, n_cell_rows);
     OGG_REQUIRE(ws && (size_t)ws_bytes >= need, OGG_EARG, "displaced-pole quadrature workspace too small: %ld < %zu bytes", ws_bytes, need);
@@ -450,6 +485,19 @@ inline int plan_dquad(int arc_form, int order, const DpGeom& g, double Re, long 
     p.j0 = j0, p.n_cell_rows = n_cell_rows, p.n_dx_rows = n_dx_rows;
     p.n_rows = M * n_cell_rows + 1, p.n_cols = M * g.ni + 1;
     p.n_strips = dq_strips(order, g.ni);
+    p.u_first = 0, p.n_src_cols = p.n_cols, p.c_first = 0, p.c_end = g.ni, p.sym = 0;
+    if (symmetry && arc_form == DP_ARC_CHORD && g.ni % 2 == 0 && g.ni >= 4) {
+        double t = fmod(g.lam_pole - g.lon0, 360.0);
+        if (t < 0.0) t += 360.0;
+        const double ic = t * (double)g.ni / 360.0;
+        if (ic == floor(ic) && ic >= 0.0 && ic <= (double)g.ni) {   // the meridian of the displaced pole is a node column
+            long a = (long)ic % g.ni;
+            if (a > g.ni / 2) a -= g.ni / 2;
+            p.sym = 1, p.c_first = a, p.c_end = a + g.ni / 2;
+            p.u_first = M * a, p.n_src_cols = M * (g.ni / 2) + 1;
+            p.n_strips = (p.n_src_cols - 1 + DQ_COLS - 1) / DQ_COLS;
+        }
+    }
     p.gx = (p.n_strips + DQ_WAVES - 1) / DQ_WAVES;
     // Cell rows per chunk.  A wave walks M rpc + 1 lattice rows (the first one recomputed), and the launch runs in ROUNDS of as many
     // waves as the chip holds: the literal form, at 2 waves per SIMD, 2048 -- so the time goes as rounds x lattice rows per wave, and the
@@ -673,15 +721,14 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
     constexpr int M = N - 1, F = N, NV = F + 1;
     constexpr unsigned ALL = (1u << (2 * F)) - 1u;
     const int lane = threadIdx.x & 63;
-    const long u0 = strip * DQ_COLS;
-    if (u0 >= p.n_cols - 1) return;              // wave-uniform: nothing but another strip's halo column (n_cols >= 2)
-    const long u = u0 + lane;                    // this lane's lattice column
-    const bool valid = u < p.n_cols;
-    const long uc = valid ? u : p.n_cols - 1;
-    const long ci = uc / M;                      // cell
-    const bool cell_start = valid && (uc % M == 0);
-    const bool out_lane = cell_start && ci < p.g.ni && lane <= 63 - M;
-    const bool dy_edge = cell_start && ci == p.g.ni;    // first node column of cell nx: dyq[.][nx]
+    const DqLane dl = dq_lane(p, M, strip, lane, DQ_COLS);
+    if (!dl.active) return;                       // wave-uniform
+    const bool valid = dl.valid;
+    const long uc = dl.uc, u = dl.uc;             // this lane's lattice column
+    const long ci = dl.ci;                        // cell
+    const bool out_lane = dl.out_lane, dy_edge = dl.dy_edge;
+    const bool sym = (ARC == DP_ARC_CHORD) && p.sym;
+    const long cm = dl.cm, pm = dl.pm;
     const DpConst c = dp_const(p.g);
     const double reps = 1.0 / p.eps;
     const double* __restrict__ row_tab = p.row_tab;   // written by the tables kernel of this call, read-only here: scalar loads
@@ -776,11 +823,20 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
                 const long out_r = r0 + k - 1;
                 const double d = (N == 2) ? (1.0 / 2.0) : (1.0 / 12.0);
                 if (out_lane) {
+                    const double da = (d * d * ysum) * p.Re * p.Re;                                   // OGG:597
                     p.dxq[out_r * p.g.ni + ci] = dxv;
-                    p.dyq[out_r * (p.g.ni + 1) + ci] = qavg_1d<N>(dyc) * p.Re;                        // OGG:595,599
-                    p.daq[out_r * p.g.ni + ci] = (d * d * ysum) * p.Re * p.Re;                        // OGG:597
+                    p.daq[out_r * p.g.ni + ci] = da;
+                    if (sym) p.dxq[out_r * p.g.ni + cm] = dxv, p.daq[out_r * p.g.ni + cm] = da;
                 }
-                if (dy_edge) p.dyq[out_r * (p.g.ni + 1) + p.g.ni] = qavg_1d<N>(dyc) * p.Re;
+                if (out_lane || dy_edge) {
+                    const double dyv = qavg_1d<N>(dyc) * p.Re;                                        // OGG:595,599
+                    double* __restrict__ row = p.dyq + out_r * (p.g.ni + 1);
+                    row[ci] = dyv;
+                    if (sym) {
+                        row[pm] = dyv;
+                        if (pm == 0) row[p.g.ni] = dyv;
+                    }
+                }
             }
             if (k < nc) {
                 if (jj == 0) {
@@ -793,7 +849,9 @@ OGG_DEV void dpole_quad_body(const DpQuadParams& p, long strip, long chunk) {
 #pragma unroll
                 for (int q = 0; q < N; ++q) dyc[q] = (jj == q) ? hj : dyc[q];
             } else if (own_top && out_lane) {     // L = M nc: the j = ny lattice row, dxq only
-                p.dxq[(r0 + nc) * p.g.ni + ci] = qavg_1d<N>(ah) * p.Re;
+                const double dxt = qavg_1d<N>(ah) * p.Re;
+                p.dxq[(r0 + nc) * p.g.ni + ci] = dxt;
+                if (sym) p.dxq[(r0 + nc) * p.g.ni + cm] = dxt;
             }
         }
         pend = pend_next;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #define OGG_DEV __device__ __forceinline__
+#define OGG_HD __host__ __device__ __forceinline__   // index arithmetic shared by a kernel and its host-side check
 
 namespace ogg {
 

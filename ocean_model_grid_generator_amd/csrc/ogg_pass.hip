@@ -30,6 +30,7 @@
 // entry points.
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "ogg_bipolar_dev.h"
 #include "ogg_dpole_dev.h"
@@ -133,7 +134,7 @@ struct PassBParams {
     long mesh_gx, n_mesh;
     QuadParams q;
     QuadRange guard, fast;
-    long gx, n_guard, n_fast;
+    long n_guard, n_fast;
     DpMeshParams dm;        // displaced-pole cap: mesh + unwrap + angle ...
     long n_dmesh;
     DpQuadParams dq;        // ... and its quadrature in the chord form (the literal form is launch D)
@@ -193,10 +194,10 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
         dpole_mesh_body(a.dm, lds.dmesh, t % a.dm.gx, t / a.dm.gx);
     } else if (role == ROLE_BP_GUARD) {
         asm volatile("; role: guarded quadrature strips" ::: "memory");
-        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
+        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.guard.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.guard.gx);
     } else if (role == ROLE_BP_FAST) {
         asm volatile("; role: quadrature strips" ::: "memory");
-        bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.gx);
+        bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.fast.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.fast.gx);
     } else if (role == ROLE_DP_QUAD) {
         const long strip = (b % a.dq.gx) * DQ_WAVES + (threadIdx.x >> 6), chunk = b / a.dq.gx;
         if (a.dq_order == 2)
@@ -221,7 +222,7 @@ long env_long(const char* name, long dflt) {
     return e ? atol(e) : dflt;
 }
 
-LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone) {
+LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone, bool light = false) {
     LatlonShare s{};
     s.gx = latlon_gx(ni1);
     s.strip_lo = lo, s.strip_hi = hi;
@@ -233,9 +234,13 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     s.points = points;
     // measured optima (1/8 degree, shares 1, 1/2, 1/4, 1/8 = 19.8, 9.9, 5, 2.5 M points): 60, 90, 90-120, 120 -- the smaller the share,
     // the shorter the VALU work the strips can hide behind, so they need more of the write bandwidth
+    // `light`: the caps' columns are mirrored (OGG_SYM_MIRROR: a third of the cap arithmetic): a launch that no longer fills the chip
+    // with VALU work for as long wants more of it writing -- half and quarter of the 1/8 degree grid 180 (measured: 0.1229 -> 0.1133 ms,
+    // 0.0583 -> 0.0566 ms), the whole grid and an eighth as before
     long max_wg = alone ? 2048
                         : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", 90)
-                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", 90) : env_long("OGG_PASS_LL_WG_SMALL", 120)));
+                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", light ? 180 : 90)
+                                                                   : env_long("OGG_PASS_LL_WG_SMALL", (light && points >= 4000000) ? 180 : 120)));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
     s.gy = gy < 1 ? 1 : gy;
@@ -297,8 +302,8 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
     QuadPlan& qp = P.qp;
     A.ll = ll, B.ll = ll;
     if (have_cap) {
-        A.mesh = MeshParams{cap->Ni, cap->Nj, cap->lat0_bp, cap->lon_bp, cap->j0, cap->n_pt_rows, cap->x, cap->y, nullptr, nullptr, cap->angle, MESH_ROWS};
-        const dim3 mg = mesh_grid(A.mesh);
+        A.mesh = MeshParams{cap->Ni, cap->Nj, cap->lat0_bp, cap->lon_bp, cap->j0, cap->n_pt_rows, cap->x, cap->y, nullptr, nullptr, cap->angle, MESH_ROWS, {}};
+        const dim3 mg = mesh_grid(A.mesh, ogg::cap_symmetry(cap->symmetry) ? 1 : 0);
         A.mesh_gx = mg.x, A.n_mesh = (long)mg.x * mg.y;
     }
     if (have_quad) {
@@ -307,12 +312,13 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         QuadParams p{};
         p.nx = cap->Ni, p.ny = cap->Nj, p.lat0_bp = cap->lat0_bp, p.lon_bp = cap->lon_bp, p.rp = cap->rp, p.Re = cap->Re, p.j0 = cap->j0;
         p.dxq = cap->dx, p.dyq = cap->dy, p.daq = cap->area, p.q = make_nodes(N);
-        if (int e = plan_quad<N>(p, cap->n_pt_rows, cap->n_cell_rows, guard_k, cap->workspace, cap->workspace_bytes, qp)) return e;
+        if (int e = plan_quad<N>(p, cap->n_pt_rows, cap->n_cell_rows, guard_k, ogg::cap_symmetry(cap->symmetry) ? 1 : 0, cap->workspace,
+                                 cap->workspace_bytes, qp))
+            return e;
         A.q = qp.p, B.q = qp.p;
         A.n_tab = tables_blocks<N>(qp.p);
-        B.gx = qp.gx;
-        B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.gx * qp.guard.gy : 0;
-        B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.gx * qp.fast.gy : 0;
+        B.guard = qp.guard, B.n_guard = qp.has_guard ? (long)qp.guard.gx * qp.guard.gy : 0;
+        B.fast = qp.fast, B.n_fast = qp.has_fast ? (long)qp.fast.gx * qp.fast.gy : 0;
     }
     DpQuadParams& dq = P.dq;
     if (have_dp) {   // workspace of the band: [mesh words][quadrature tables and words]
@@ -326,7 +332,7 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         if (have_dquad) {
             if (int e = plan_dquad(scap->arc_form, scap->order, g, scap->Re, scap->j0, scap->n_pt_rows, scap->n_cell_rows, scap->dx, scap->dy,
                                    scap->area, static_cast<char*>(scap->workspace) + mesh_ws, scap->workspace_bytes - mesh_ws,
-                                   make_nodes(scap->order), dq))
+                                   make_nodes(scap->order), dq, ogg::cap_symmetry(scap->symmetry) ? 1 : 0))
                 return e;
             A.dq = dq, A.dq_order = scap->order;
             A.n_dq_tab = scap->order == 2 ? dpole_quad_tables_blocks<2>(dq) : dpole_quad_tables_blocks<4>(dq);
@@ -371,7 +377,7 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         const char* ord = getenv("OGG_PASS_ORDER");
         for (int k = 0; k < N_ROLES; ++k)
             B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : dflt[k];
-        B.share = make_share(ll, s1, n_strips_ll, ni1, false);
+        B.share = make_share(ll, s1, n_strips_ll, ni1, false, have_cap && ogg::cap_symmetry(cap->symmetry));
         // helper workgroups for the lat-lon strips at the end of the launch (ogg_latlon_fused_dev.h): the claim counters live in the
         // bipolar cap's workspace and are zeroed by launch A with its tables
         // (measured: 1/8 degree whole grid 0.246 -> 0.237 ms, 1/16 degree 1.23 -> 1.19; half, a quarter, an eighth of the 1/8 degree grid
@@ -593,6 +599,81 @@ int run_pass_pipe(PassPipe& H, void** events5, double* alg_bytes4, void* stream)
 }
 
 }  // namespace
+
+// Host-side replay of the column spaces of the mirrored kernels (the same quad_lane / mesh_lane / dq_lane the kernels call): how many
+// times every cell and every node column of one row is written, and how many cells / columns are evaluated.  No GPU involved.
+extern "C" int ogg_symmetry_coverage(int which, int order, long n, double lon0, double lon_dp, int symmetry, int* cell_writes, int* col_writes,
+                                     long* evaluated) {
+    OGG_REQUIRE(which >= 0 && which <= 2 && n > 0 && col_writes && evaluated && (which == 1 || cell_writes), OGG_EARG,
+                "ogg_symmetry_coverage: bad argument");
+    const int sym = ogg::cap_symmetry(symmetry) ? 1 : 0;
+    for (long k = 0; k <= n; ++k) col_writes[k] = 0;
+    if (cell_writes)
+        for (long k = 0; k < n; ++k) cell_writes[k] = 0;
+    *evaluated = 0;
+    auto bump = [](int* w, long a, long b, long c, long d) {   // one lane writes its value to a, b, c, d: every DISTINCT target once
+        w[a] += 1;
+        if (b != a) w[b] += 1;
+        if (c != a && c != b) w[c] += 1;
+        if (d != a && d != b && d != c) w[d] += 1;
+    };
+    if (which == 0) {
+        const QuadCols cs = quad_cols(n, sym);
+        const long h2 = n / 2, n_strips = (cs.total + QS_CELLS - 1) / QS_CELLS;
+        for (long strip = 0; strip < n_strips; ++strip)
+            for (int lane = 0; lane < 64; ++lane) {
+                const QuadLane q = quad_lane(cs, strip, lane, QS_CELLS);
+                if (!q.active) continue;
+                if (q.col_lane) {
+                    *evaluated += 1;
+                    if (q.img_col) bump(col_writes, q.ci, h2 - q.ci, h2 + q.ci, n - q.ci);
+                    else col_writes[q.ci] += 1;
+                }
+                if (q.cell_lane) {
+                    if (q.img_cell) bump(cell_writes, q.ci, h2 - 1 - q.ci, h2 + q.ci, n - 1 - q.ci);
+                    else cell_writes[q.ci] += 1;
+                }
+            }
+    } else if (which == 1) {
+        const MeshCols mc = mesh_cols(n, sym);
+        const long h2 = n / 2;
+        for (long w = 0; w < mc.w_end[3]; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                const MeshLane m = mesh_lane(mc, n, w, lane, MESH_OUT);
+                if (!m.out) continue;
+                *evaluated += 1;
+                if (m.img) bump(col_writes, m.i, h2 - m.i, h2 + m.i, n - m.i);
+                else col_writes[m.i] += 1;
+            }
+    } else {
+        OGG_REQUIRE(order == 2 || order == 4, OGG_EORDER, "order not coded");
+        DpQuadParams p{};
+        const size_t ws_bytes = dq_workspace_bytes(order, n, 4);
+        std::vector<char> ws(ws_bytes);   // plan_dquad carves pointers out of it; nothing is dereferenced here
+        if (int e = plan_dquad(DP_ARC_CHORD, order, DpGeom{n, 8, lon0, -78.0, lon_dp, 0.2}, kReDefault, 0, 4, 4, nullptr, nullptr, nullptr, ws.data(),
+                               (long)ws_bytes, make_nodes(order), p, sym))
+            return e;
+        const int M = order - 1;
+        for (long strip = 0; strip < p.n_strips + 1; ++strip)
+            for (int lane = 0; lane < 64; ++lane) {
+                const DqLane q = dq_lane(p, M, strip, lane, DQ_COLS);
+                if (!q.active) continue;
+                if (q.out_lane) {
+                    *evaluated += 1;
+                    cell_writes[q.ci] += 1;
+                    if (p.sym && q.cm != q.ci) cell_writes[q.cm] += 1;
+                }
+                if (q.out_lane || q.dy_edge) {
+                    col_writes[q.ci] += 1;
+                    if (p.sym) {
+                        if (q.pm != q.ci) col_writes[q.pm] += 1;
+                        if (q.pm == 0 && q.ci != n) col_writes[n] += 1;
+                    }
+                }
+            }
+    }
+    return OGG_OK;
+}
 
 extern "C" long ogg_dpole_band_workspace_bytes(int order, long Ni, long n_pt_rows) {
     if ((order != 2 && order != 4) || Ni <= 0 || n_pt_rows < 0) return 0;

@@ -77,8 +77,21 @@ def bipolar_projection(lamg, phig, lon_bp, rp, metrics_only=False):
     return hi, hj
 
 
-def generate_bipolar_cap_mesh(Ni, Nj_ncap, lat0_bp, lon_bp, ensure_nj_even=True):
-    """OGG:103-122."""
+def _sym(symmetry):
+    """``symmetry`` of the cap functions (not in the reference): None -> the library's default (mirrored columns unless OGG_CAP_SYMMETRY=0),
+    True / "mirror" -> OGG_SYM_MIRROR, False / "none" -> OGG_SYM_NONE: every column evaluated, as the reference does."""
+    if symmetry is None:
+        return L.SYM_DEFAULT
+    if symmetry in (True, "mirror"):
+        return L.SYM_MIRROR
+    if symmetry in (False, "none"):
+        return L.SYM_NONE
+    raise ValueError("symmetry must be None, True / 'mirror' or False / 'none', not %r" % (symmetry,))
+
+
+def generate_bipolar_cap_mesh(Ni, Nj_ncap, lat0_bp, lon_bp, ensure_nj_even=True, symmetry=None):
+    """OGG:103-122.  ``symmetry`` (not in the reference): see _sym; mirrored, a quarter of the columns (+ the neighbourhoods of the pole
+    meridians and of the fold lines) is evaluated and written to its images (csrc/ogg_bipolar_dev.h, MeshCols)."""
     print("Generating bipolar grid bounded at latitude ", lat0_bp)
     if Nj_ncap % 2 != 0 and ensure_nj_even:
         print("   Supergrid has an odd number of area cells!")
@@ -87,7 +100,7 @@ def generate_bipolar_cap_mesh(Ni, Nj_ncap, lat0_bp, lon_bp, ensure_nj_even=True)
     Ni, Nj_ncap = int(Ni), int(Nj_ncap)
     lams, phis = _new(Nj_ncap + 1, Ni + 1), _new(Nj_ncap + 1, Ni + 1)
     h_i_inv, h_j_inv = _new(Nj_ncap + 1, Ni), _new(Nj_ncap, Ni + 1)
-    L.call("ogg_bipolar_cap_mesh", Ni, Nj_ncap, float(lat0_bp), float(lon_bp), L.ptr(lams), L.ptr(phis), L.ptr(h_i_inv),
+    L.call("ogg_bipolar_cap_mesh_sym", Ni, Nj_ncap, float(lat0_bp), float(lon_bp), _sym(symmetry), L.ptr(lams), L.ptr(phis), L.ptr(h_i_inv),
            L.ptr(h_j_inv))
     print("   number of js=", phis.shape[0])
     return lams, phis, h_i_inv, h_j_inv
@@ -102,13 +115,15 @@ def bipolar_cap_ij_array(i, j, Ni, Nj_ncap, lat0_bp, lon_bp, rp):
     return hi, hj
 
 
-def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=_default_Re):
-    """OGG:136-188 (kernel bipolar_quad_kernel: the lattice is evaluated and reduced on chip)."""
+def bipolar_cap_metrics_quad_fast(order, nx, ny, lat0_bp, lon_bp, rp, Re=_default_Re, symmetry=None):
+    """OGG:136-188 (kernel bipolar_quad_kernel: the lattice is evaluated and reduced on chip).  ``symmetry`` (not in the reference): see
+    _sym; mirrored, the rows below 88.2 degrees are evaluated on the cells [0, nx/4) and next to the fold lines and written to their images
+    (csrc/ogg_bipolar_dev.h, QuadCols)."""
     print("   Calculating bipolar cap metrics via quadrature ...")
     nx, ny = int(nx), int(ny)
     dxq, dyq, daq = _new(ny + 1, nx), _new(ny, nx + 1), _new(ny, nx)
-    L.call("ogg_bipolar_cap_metrics_quad", int(order), nx, ny, float(lat0_bp), float(lon_bp), float(rp), float(Re), L.ptr(dxq),
-           L.ptr(dyq), L.ptr(daq))
+    L.call("ogg_bipolar_cap_metrics_quad_sym", int(order), nx, ny, float(lat0_bp), float(lon_bp), float(rp), float(Re), _sym(symmetry),
+           L.ptr(dxq), L.ptr(dyq), L.ptr(daq))
     return dxq, dyq, daq
 
 
@@ -405,7 +420,7 @@ def default_dp_arc():
     return arc
 
 
-def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_default_Re, arc_form=None):
+def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_default_Re, arc_form=None, symmetry=None):
     """OGG:565-601 (kernels dpole_quad_tables / dpole_quad_kernel: the lattice is evaluated and reduced on chip).
     ``arc_form`` (not in the reference): how the great-arc distance of two probes of the finite-difference stencil is taken.
     "chord" (the default, also OGG_DP_ARC): from the probes' positions on the sphere (cross product; no longitude, no unwrap);
@@ -413,13 +428,15 @@ def displacedPoleCap_metrics_quad(order, nx, ny, lon0, lat0, lon_dp, r_dp, Re=_d
     Same stencil, same quadrature.  Against the exact value of the reference's own formula (50-digit evaluation,
     tests/golden/truth_table.npz, 1/8 degree cap of BASELINE config 4) the fp64 reference itself is 1.4e-9 / 9.0e-10 / 1.2e-9
     (dx / dy / area, max relative) away, the literal form 1.4e-9 / 8.5e-10 / 1.2e-9 and the chord form 7.6e-10 / 2.7e-10 / 8.3e-10
-    (profiles/r04_truth_table.json): the chord form is the more accurate one and ~6x cheaper, hence the default."""
+    (profiles/r04_truth_table.json): the chord form is the more accurate one and ~6x cheaper, hence the default.
+    ``symmetry`` (not in the reference): see _sym; mirrored (chord form, the displaced pole's meridian on a node column), the half of the
+    columns on one side of that meridian is evaluated and written to its mirror images (csrc/ogg_dpole_dev.h, DpQuadParams)."""
     print("   Calculating displaced pole cap metrics via quadrature ...")
     nx, ny = int(nx), int(ny)
     form = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[arc_form or default_dp_arc()]
     dxq, dyq, daq = _new(ny + 1, nx), _new(ny, nx + 1), _new(ny, nx)
-    L.call("ogg_displaced_pole_metrics_quad_form", form, int(order), nx, ny, float(lon0), float(lat0), float(lon_dp), float(r_dp),
-           float(Re), L.ptr(dxq), L.ptr(dyq), L.ptr(daq))
+    L.call("ogg_displaced_pole_metrics_quad_form_sym", form, _sym(symmetry), int(order), nx, ny, float(lon0), float(lat0), float(lon_dp),
+           float(r_dp), float(Re), L.ptr(dxq), L.ptr(dyq), L.ptr(daq))
     return dxq, dyq, daq
 
 
@@ -624,7 +641,7 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
          no_changing_meta=False, enhanced_equatorial=0, debug=False, grids="all", match_dy=(), skip_metrics=False,
          ensure_nj_even=False, shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0,
          mercator_upper_lat=-99.0, south_ocean_lower_lat=-99.0, south_ocean_upper_lat=-99.0, no_south_cap=False,
-         return_arrays=False, path=None, dp_arc=None):
+         return_arrays=False, path=None, dp_arc=None, cap_symmetry=None):
     """Build the supergrid and write it.  Same flags as the reference's main() (OGG:855-1449); the defaults of ``grids`` and
     ``match_dy`` are the argparse defaults (the reference's own function defaults fail its own validation, OGG:870-888).
 
@@ -634,8 +651,10 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
     stitching.  ``path="functions"`` (or OGG_MAIN_PATH=functions) runs the reference's own sequence of calls instead, one host-array
     function after the other (main_function_level): the same bits, for checking.  ``dp_arc`` (or OGG_DP_ARC): arc form of the
     displaced-pole quadrature, "chord" (default; DESIGN.md section 2: closer to the exact value of the reference's formula than the fp64
-    reference is) or "literal" (the reference's operation sequence).  ``return_arrays=True`` additionally returns the six stitched
-    fields and the sub-grid pieces (used by tests)."""
+    reference is) or "literal" (the reference's operation sequence).  ``cap_symmetry`` (or OGG_CAP_SYMMETRY=0): None / True: the caps
+    are evaluated on the columns that determine the rest and mirrored (_sym; DESIGN.md section 2: a mirrored value is as far from the exact
+    value of the reference's formula as the reference's own), False: every column, as the reference does.  ``return_arrays=True``
+    additionally returns the six stitched fields and the sub-grid pieces (used by tests)."""
     import time
 
     path = path or os.environ.get("OGG_MAIN_PATH", "pass")
@@ -644,7 +663,8 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
         return main_function_level(inverse_resolution, gridfilename, r_dp, lon_dp, lat_dp, exfracdp, south_cutoff_row, south_cutoff_ang,
                                    reproduce_MIDAS_grids, write_subgrid_files, plotem, no_changing_meta, enhanced_equatorial, debug, grids,
                                    match_dy, skip_metrics, ensure_nj_even, shift_equator_to_u_point, bipolar_lower_lat, mercator_lower_lat,
-                                   mercator_upper_lat, south_ocean_lower_lat, south_ocean_upper_lat, no_south_cap, return_arrays, dp_arc)
+                                   mercator_upper_lat, south_ocean_lower_lat, south_ocean_upper_lat, no_south_cap, return_arrays, dp_arc,
+                                   cap_symmetry)
     from . import supergrid as SG
 
     _validate_flags(match_dy, r_dp, lat_dp)
@@ -655,7 +675,7 @@ def main(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=0.0, lon_dp=80.
                             no_south_cap=no_south_cap, enhanced_equatorial=enhanced_equatorial, match_dy=match_dy, grids=grids,
                             shift_equator_to_u_point=shift_equator_to_u_point, bipolar_lower_lat=bipolar_lower_lat,
                             mercator_lower_lat=mercator_lower_lat, mercator_upper_lat=mercator_upper_lat,
-                            south_ocean_lower_lat=south_ocean_lower_lat, dp_arc=dp_arc)
+                            south_ocean_lower_lat=south_ocean_lower_lat, dp_arc=dp_arc, cap_symmetry=cap_symmetry)
     import torch
     g = SG.Supergrid(plan, device="cuda:%d" % torch.cuda.current_device())
     for s in plan.subs:
@@ -737,7 +757,7 @@ def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=
                         no_changing_meta=False, enhanced_equatorial=0, debug=False, grids="all", match_dy=(), skip_metrics=False,
                         ensure_nj_even=False, shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0,
                         mercator_upper_lat=-99.0, south_ocean_lower_lat=-99.0, south_ocean_upper_lat=-99.0, no_south_cap=False,
-                        return_arrays=False, dp_arc=None):
+                        return_arrays=False, dp_arc=None, cap_symmetry=None):
     """The reference's own sequence of calls (OGG:855-1449), every callee a host-array function of this module (numpy in, numpy
     out, one staged device call each) and the stitching on the host: what a user gets who swaps the reference's module for this
     one function by function.  main() produces the same bits from one device-resident pass."""
@@ -823,11 +843,11 @@ def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=
         if "bp" in match_dy:
             print("   Match dy at bipolar cap joint")
             Nj_ncap = int(0.5 + (90.0 - lat0_bp) / DeltaPhiMerc_no)
-        lamBP, phiBP, _, _ = generate_bipolar_cap_mesh(Ni, Nj_ncap, lat0_bp, lon_bp, ensure_nj_even=ensure_nj_even)
+        lamBP, phiBP, _, _ = generate_bipolar_cap_mesh(Ni, Nj_ncap, lat0_bp, lon_bp, ensure_nj_even=ensure_nj_even, symmetry=cap_symmetry)
         rp = np.tan(0.5 * (90 - lat0_bp) * PI_180)
         dxBP, dyBP, areaBP = _minus_ones(lamBP)
         if calculate_metrics:
-            dxBP, dyBP, areaBP = bipolar_cap_metrics_quad_fast(5, phiBP.shape[1] - 1, phiBP.shape[0] - 1, lat0_bp, lon_bp, rp)
+            dxBP, dyBP, areaBP = bipolar_cap_metrics_quad_fast(5, phiBP.shape[1] - 1, phiBP.shape[0] - 1, lat0_bp, lon_bp, rp, symmetry=cap_symmetry)
             print("   CHECK_metrics_hquad: % errors in (area, lat arc, lon arc1, lon arc2)",
                   metrics_error(dxBP, dyBP, areaBP, Ni, lat0_bp, 90.0, bipolar=True))
         angleBP = angle_x(lamBP, phiBP)
@@ -886,7 +906,7 @@ def main_function_level(inverse_resolution, gridfilename="ocean_hgrid.nc", r_dp=
             angleSC = angle_x(lamSC, phiSC)
             dxSC, dySC, areaSC = _minus_ones(lamSC)
             if calculate_metrics:
-                dxSC, dySC, areaSC = displacedPoleCap_metrics_quad(4, Ni, Nj_scap, lon0, lat0_SC, lon_dp, r_dp, arc_form=dp_arc)
+                dxSC, dySC, areaSC = displacedPoleCap_metrics_quad(4, Ni, Nj_scap, lon0, lat0_SC, lon_dp, r_dp, arc_form=dp_arc, symmetry=cap_symmetry)
                 poles_i = int(Ni * np.mod(lon_dp - lon0, 360) / 360.0)
                 print("   CHECK_metrics_hquad: % errors in (area, lat arc, lon arc)",
                       metrics_error(dxSC, dySC, areaSC, Ni, lat1=lat0_SC, lat2=-90.0, displaced_pole=poles_i,

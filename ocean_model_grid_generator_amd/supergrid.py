@@ -92,18 +92,20 @@ class SupergridPlan(object):
     def __init__(self, inverse_resolution, r_dp=0.0, lon_dp=80.0, lat_dp=-99.0, exfracdp=0.49, south_cutoff_row=0, south_cutoff_ang=-90.0,
                  skip_metrics=False, ensure_nj_even=False, no_south_cap=False, enhanced_equatorial=0, match_dy=(), grids="all",
                  shift_equator_to_u_point=True, bipolar_lower_lat=-99.0, mercator_lower_lat=-99.0, mercator_upper_lat=-99.0,
-                 south_ocean_lower_lat=-99.0, Re=ogg._default_Re, mercator_axis=None, dp_arc=None):
+                 south_ocean_lower_lat=-99.0, Re=ogg._default_Re, mercator_axis=None, dp_arc=None, cap_symmetry=None):
         """``mercator_axis`` = (y0, phi_M) lets a caller that already holds the Mercator ordinate range and axis skip the
         two device calls (the CPU tests of the band / halo logic pass values computed elsewhere).  ``dp_arc``: arc form of
         the displaced-pole quadrature, "chord" (default, or OGG_DP_ARC: the form closer to the exact value of the reference's formula,
         DESIGN.md section 2) or "literal" (the reference's operation sequence; a fourth launch of the pass).  ``exfracdp=None``:
-        main()'s own default 0.28*7/4 (OGG:891-892)."""
+        main()'s own default 0.28*7/4 (OGG:891-892).  ``cap_symmetry``: None (the library's default: mirrored columns unless
+        OGG_CAP_SYMMETRY=0), True / "mirror", False / "none" (every column of both caps evaluated, as the reference does)."""
         import contextlib
         import io
 
         refineS, refineR = 2, inverse_resolution
         self.Re = Re
         self.dp_arc = {"literal": L.DP_ARC_LITERAL, "chord": L.DP_ARC_CHORD}[dp_arc or ogg.default_dp_arc()]
+        self.cap_symmetry = ogg._sym(cap_symmetry)   # OGG_SYM_* of include/ogg_hip.h
         self.skip_metrics = skip_metrics
         self.ensure_nj_even = ensure_nj_even
         self.south_cutoff_row, self.south_cutoff_ang = south_cutoff_row, south_cutoff_ang
@@ -555,6 +557,7 @@ class Supergrid(object):
                 if s.kind == "bipolar" and b["n"] > 0:
                     cap = L.BipolarBand()
                     cap.Ni, cap.Nj, cap.lat0_bp, cap.lon_bp, cap.rp, cap.Re, cap.order = p.Ni, s.Nj, s.lat0_bp, s.lon_bp, s.rp, p.Re, 5
+                    cap.symmetry = p.cap_symmetry
                     cap.j0, cap.n_pt_rows, cap.n_cell_rows = b["lo"], b["n"], b["n_cell"]
                     cap.x, cap.y, cap.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
                     cap.dx = b["dx"].data_ptr()
@@ -564,7 +567,7 @@ class Supergrid(object):
                 elif s.kind == "dpole" and b["n"] > 0:
                     scap = L.DpoleBand()
                     scap.Ni, scap.Nj, scap.lon0, scap.lat0, scap.lon_dp, scap.r_dp, scap.Re = p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp, p.Re
-                    scap.order, scap.arc_form = 4, p.dp_arc
+                    scap.order, scap.arc_form, scap.symmetry = 4, p.dp_arc, p.cap_symmetry
                     scap.j0, scap.n_pt_rows, scap.n_cell_rows = s.row0 + b["lo"], b["n"], b["n_cell"]
                     scap.x, scap.y, scap.angle = b["x"].data_ptr(), b["y"].data_ptr(), b["angle_dx"].data_ptr()
                     scap.dx = b["dx"].data_ptr()
@@ -688,8 +691,9 @@ class Supergrid(object):
                 self._timed("tile_latlon", lambda: L.call("ogg_tile_latlon_dev", rows, ni1, self._p(b["axis"], s.row0 + b["lo"]),
                                                           self.lon1d.data_ptr(), b["x"].data_ptr(), b["y"].data_ptr(), st))
             elif s.kind == "bipolar":
-                self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
-                                                           b["x"].data_ptr(), b["y"].data_ptr(), None, None, b["angle_dx"].data_ptr(), st))
+                self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_sym_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
+                                                           p.cap_symmetry, b["x"].data_ptr(), b["y"].data_ptr(), None, None,
+                                                           b["angle_dx"].data_ptr(), st))
             elif s.kind == "dpole":   # mesh, unwrap and angle_dx in one launch (its look-back words: the head of the band's workspace)
                 self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_angle_ws_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
                                                          s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(),
@@ -755,13 +759,13 @@ class Supergrid(object):
             else:
                 if not p.skip_metrics:
                     if s.kind == "bipolar":
-                        self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_ws_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
-                                                                   s.rp, p.Re, b["lo"], b["n"], b["n_cell"], b["dx"].data_ptr(),
+                        self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_sym_ws_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
+                                                                   s.rp, p.Re, b["lo"], b["n"], b["n_cell"], p.cap_symmetry, b["dx"].data_ptr(),
                                                                    b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
                                                                    b["ws_bytes"], st))
                     else:
                         j0 = s.row0 + b["lo"]
-                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_form_ws_dev", p.dp_arc, 4, p.Ni, s.Nj, p.lon0,
+                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_form_sym_ws_dev", p.dp_arc, p.cap_symmetry, 4, p.Ni, s.Nj, p.lon0,
                                                                  s.lat0, s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
                                                                  b["dy"].data_ptr() if b["n_cell"] else None,
                                                                  b["area"].data_ptr() if b["n_cell"] else None,

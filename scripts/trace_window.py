@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""The launches of a bench run's TIMED REGION in a rocprofv3 kernel trace of that run.
+
+    python scripts/trace_window.py <tag> <workload> <stats_dir> <bench_stdout>
+
+`rocprofv3 --kernel-trace --stats` averages every launch of the command: set-up, the clock ramp, the autotune candidates, the power probe
+and the per-kernel pass included (round 4: 303 launches of pass_b for 200 timed ones, mean 235 us against a median of 229).  bench.py stamps
+its timed region on three host clocks (`timed_region_clock_ns`); this script takes the clock on which the region holds K launches of the
+dominant kernel, and writes, per kernel, count / mean / median / p10 / p90 of the launches INSIDE the region beside the all-launch count and
+mean, to profiles/<tag>_kernel_stats_<workload>.csv.  `alg_bytes / window median / 8 TB/s` is then the roofline fraction the profile itself
+supports, to be compared with the bench line's event-based `roofline.frac` and with `roofline.frac_step`."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def clean(name):
+    return re.sub(r"\(anonymous namespace\)::|^void ", "", name).split("(")[0]
+
+
+def pct(v, q):
+    v = sorted(v)
+    return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
+
+
+def main():
+    tag, workload, stats_dir, bench_out = sys.argv[1:5]
+    trace = glob.glob(os.path.join(stats_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
+    line = [l for l in open(bench_out).read().splitlines() if l.startswith("{")][-1]
+    bench = json.loads(line)
+    steps, region = bench["steps"], bench["timed_region_clock_ns"]
+    rows = [(clean(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace))]
+    dom = bench["roofline"]["kernel"].split("<")[0]
+    best = None
+    for clock, (a, b) in region.items():
+        n = sum(1 for k, s, e in rows if k.startswith(dom) and s >= a and e <= b + 2_000_000)   # the last launch may end after the host's stamp
+        if best is None or abs(n - steps) < abs(best[1] - steps):
+            best = (clock, n, a, b)
+    clock, n_dom, a, b = best
+    per_all, per_win = {}, {}
+    for k, s, e in rows:
+        per_all.setdefault(k, []).append(e - s)
+        if s >= a and e <= b + 2_000_000:
+            per_win.setdefault(k, []).append(e - s)
+    out = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (tag, workload))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# rocprofv3 --kernel-trace of `%s`; timed region = %d steps found on the %s clock (%d launches of %s inside); ns"
+                    % (" ".join(bench.get("argv", ["bench.py", "--workload", workload])), steps, clock, n_dom, dom)])
+        w.writerow(["Name", "Calls_all", "Mean_all_ns", "Calls_region", "Mean_region_ns", "Median_region_ns", "P10_region_ns", "P90_region_ns",
+                    "Total_region_ns"])
+        for k in sorted(per_all, key=lambda k: -sum(per_win.get(k, [0]))):
+            va, vw = per_all[k], per_win.get(k, [])
+            w.writerow([k, len(va), round(sum(va) / len(va)), len(vw)] +
+                       ([round(sum(vw) / len(vw)), pct(vw, 0.5), pct(vw, 0.1), pct(vw, 0.9), sum(vw)] if vw else ["", "", "", "", 0]))
+    # cross-check against the bench line: the region's kernels must fit into its wall time, and the dominant launch's median must agree
+    # with the event-based duration
+    busy = sum(sum(v) for v in per_win.values())
+    rep = {"clock": clock, "launches_of_dominant_kernel_in_region": n_dom, "steps": steps,
+           "region_wall_ms_per_step": (b - a) / steps / 1e6, "bench_ms_per_step": bench["ms_per_step"],
+           "kernel_time_in_region_ms_per_step": busy / steps / 1e6}
+    dv = [v for k, v in per_win.items() if k.startswith(dom)]
+    if dv:
+        med = pct(dv[0], 0.5)
+        ev = (bench.get("pass_launches") or {}).get("pass_b", {})
+        rep.update({"dominant_kernel": dom, "median_region_ns": med, "bench_event_ms": ev.get("ms"), "alg_bytes": ev.get("alg_bytes"),
+                    "frac_from_trace_median": (ev["alg_bytes"] / (med * 1e-9) / 8e12) if ev.get("alg_bytes") else None,
+                    "bench_roofline_frac": bench["roofline"].get("frac"), "bench_frac_step": bench["roofline"].get("frac_step")})
+    print(json.dumps(rep))
+    json.dump(rep, open(os.path.join(ROOT, "profiles", "%s_trace_window_%s.json" % (tag, workload)), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
