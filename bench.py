@@ -280,6 +280,7 @@ def self_launch(n, argv, timeout=None):
     rank 0's ONE JSON line on stdout and return the exit code for this process: the children's if they failed, 1 if no line came."""
     import socket
     import subprocess
+    import threading
 
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -290,17 +291,39 @@ def self_launch(n, argv, timeout=None):
             port = s.getsockname()[1]
         # (the port is free NOW; somebody else may take it before torch.distributed.run binds it: one retry with another port)
         cmd = self_launch_command(n, argv, port)
+        # the ranks' stderr is passed through AS IT COMES (a reader thread: a hang at N ranks leaves its diagnostics on the terminal, and a
+        # timeout loses nothing) and kept for the one check below; stdout (rank 0's JSON line) is collected
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        err_lines, out_lines = [], []
+
+        def pump(stream, keep, echo):
+            for line in stream:
+                keep.append(line)
+                if echo:
+                    sys.stderr.write(line)
+                    sys.stderr.flush()
+
+        readers = [threading.Thread(target=pump, args=(p.stderr, err_lines, True), daemon=True),
+                   threading.Thread(target=pump, args=(p.stdout, out_lines, False), daemon=True)]
+        for th in readers:
+            th.start()
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
-        except subprocess.TimeoutExpired as exc:
-            sys.stderr.write("bench.py: the %d ranks did not finish within %s s\n" % (n, exc.timeout))
+            p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            for th in readers:
+                th.join(5)
+            sys.stderr.write("bench.py: the %d ranks did not finish within %s s (their stderr is above)\n" % (n, timeout))
             return 124
-        sys.stderr.write(p.stderr)
-        if p.returncode == 0 or attempt == 1 or not any(t in p.stderr for t in ("EADDRINUSE", "Address already in use", "address already in use")):
+        for th in readers:
+            th.join(5)
+        stdout = "".join(out_lines)
+        stderr = "".join(err_lines)
+        if p.returncode == 0 or attempt == 1 or not any(t in stderr for t in ("EADDRINUSE", "Address already in use", "address already in use")):
             break
         sys.stderr.write("bench.py: the rendezvous port %d was taken between choosing and binding it; once more with another port\n" % port)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    for l in p.stdout.splitlines():
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    for l in stdout.splitlines():
         if not l.startswith("{"):
             sys.stderr.write(l + "\n")
     if p.returncode != 0:
@@ -412,6 +435,28 @@ def main():
             for _ in range(20):
                 sg.run_pass()
             torch.cuda.synchronize()
+    # Several ranks: every rank times its OWN share on its own GPU, all at once (the job's conditions; calibrate_split timed the shares one
+    # after the other on rank 0's idle chip), the times are all-gathered, and ONE rebalancing step scales the last rank's share -- the
+    # same arithmetic on the same list on every rank, hence the same edges.  A second measurement under the new split is recorded too.
+    if args.latlon == "fused" and world > 1 and args.as_rank is None and os.environ.get("OGG_SPLIT_SELF_CALIBRATE", "1") != "0":
+        def own_us(n=200):
+            sync()
+            ta = time.perf_counter()
+            for _ in range(n):
+                sg.run_pass()
+            torch.cuda.synchronize()
+            mine = (time.perf_counter() - ta) / n * 1e6
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            return gathered
+        if plan.refine_split(own_us(), world):
+            sg.close()
+            sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
+            sg.overlap, sg.launch = bool(args.overlap), "pass"
+            for _ in range(100):
+                sg.run_pass()
+            torch.cuda.synchronize()
+            plan.split_times["self_calibration"][-1]["per_rank_us_after"] = [round(v, 3) for v in own_us()]
     sg.launch = "kernels"
     can_graph = not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
     use_graph = bool(args.graph) and can_graph

@@ -382,7 +382,9 @@ int ogg_supergrid_pass_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1
  * stream, no flag and no wait: the stream's order is the dependence.  Every pass still builds one set of tables; the first pass of a
  * plan, and a pass that records events (events5 != NULL, so that they time it), run launch A themselves; the tables the LAST pass of a
  * plan built for a successor that never came are wasted (a few microseconds).  What the caller sees is unchanged: the outputs of a run
- * are complete when `stream` has executed it, and nothing of pass k + 1 reaches an output array during pass k (the one output launch
+ * are complete when `stream` has executed it (a pass captured into a HIP graph: when a replay has executed; such a graph must not be
+ * replayed after ogg_supergrid_pass_plan_destroy, which then waits for the whole device rather than for the last stream), and nothing of
+ * pass k + 1 reaches an output array during pass k (the one output launch
  * A writes, the j = ny row of the bipolar dx, goes through the workspace and is copied by the tail launch); results are bit-identical
  * with one slot or two.  ogg_supergrid_pass_plan_destroy waits for the device. */
 int ogg_supergrid_pass_plan_dev(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,

@@ -514,15 +514,18 @@ struct PassPipe {
     int device = 0;
     hipStream_t last_stream = nullptr;      // the stream of the last pass (the plan's passes are ordered by the caller's stream)
     bool ran = false;
+    bool captured = false;                  // a pass of this plan went into a stream capture: its graph may replay on ANY stream
 
     ~PassPipe() {
         if (n_slots > 1) {
             int current = 0;
             (void)hipGetDevice(&current);
             (void)hipSetDevice(device);
-            // nothing of the plan may still be in flight when its workspaces go: wait for the stream of its last pass only (not for the
-            // whole device: other streams are none of the plan's business); a stream that no longer exists: the device, to be safe
-            if (ran && hipStreamSynchronize(last_stream) != hipSuccess) {
+            // nothing of the plan may still be in flight when its workspaces go: wait for the stream of its last pass (not for the
+            // whole device: other streams are none of the plan's business) -- unless a pass was captured: the graph's replays run on
+            // whatever stream the caller launches them on, which the plan never sees, so then the whole device; likewise when the
+            // stream no longer exists.  (A captured graph must not be replayed after the plan is destroyed: include/ogg_hip.h.)
+            if (ran && (captured || hipStreamSynchronize(last_stream) != hipSuccess)) {
                 (void)hipGetLastError();
                 (void)hipDeviceSynchronize();
             }
@@ -585,6 +588,7 @@ int run_pass_pipe(PassPipe& H, void** events5, double* alg_bytes4, void* stream)
     if (hipStreamIsCapturing(ogg::as_stream(stream), &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone) {
         const int sc = (int)(H.runs & 1ull);
         H.ready_slot = -1;
+        H.captured = true;
         return run_pass_plan_any(H.slot[sc], events5, alg_bytes4, stream, true, nullptr, 0);
     }
     const int s = (int)(H.runs & 1ull), o = s ^ 1;

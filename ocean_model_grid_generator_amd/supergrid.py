@@ -360,6 +360,34 @@ class SupergridPlan(object):
                              top_capacity=((world, cap) if cap > 0.0 else None))
         return self.split_times
 
+    def refine_split(self, per_rank_us, world, deadband=0.03):
+        """One rebalancing step from what every rank measured on its OWN GPU under the current split, all ranks running at once (the
+        conditions of the job: calibrate_split times the shares one after the other on rank 0's idle chip).  ``per_rank_us``: every
+        rank's time per pass in rank order -- the same list on every rank (bench.py all-gathers it), so every rank derives the same new
+        edges and nothing is broadcast.  The last rank's share is scaled by mean(T of the others) / T_last; inside the ``deadband`` (the
+        last rank within 3 % of the others: a timing cannot tell) the split stays.  Returns True when the split changed (band buffers must
+        be rebuilt).  The measured times and both shares are recorded in ``split_times["self_calibration"]``."""
+        if world <= 1 or self.split_times is None or len(per_rank_us) != world:
+            return False
+        t = [float(v) for v in per_rank_us]
+        others = sum(t[:-1]) / (world - 1)
+        s0 = self.subs[0]
+        old = getattr(s0, "top_capacity", None)
+        if old is not None and int(old[0]) == world:
+            cap_old = float(old[1])
+        else:
+            tail, whole = self.split_times["tail_us"], self.split_times["pass_us"]
+            cap_old = min(1.0, 1.0 - world * tail / whole) if (whole > 0 and world * tail / whole <= 0.5) else 1.0
+        ratio = others / t[-1] if t[-1] > 0 else 1.0
+        rec = {"world": world, "per_rank_us": [round(v, 3) for v in t], "share_of_last_rank_before": cap_old, "others_over_last": ratio}
+        changed = abs(ratio - 1.0) > deadband
+        cap_new = min(max(cap_old * ratio, 0.3), 1.3) if changed else cap_old
+        rec["share_of_last_rank_after"] = cap_new
+        hist = list(self.split_times.get("self_calibration", []))
+        self.set_split_times(self.split_times["tail_us"], self.split_times["pass_us"], self.split_times["source"], top_capacity=(world, cap_new))
+        self.split_times["self_calibration"] = hist + [rec]
+        return changed and cap_new != cap_old
+
     def south_cut(self, sc_y0=None):
         """(rows cut from the southern cap, rows cut from the Southern Ocean piece, cap removed) by --south_cutoff_row / _ang,
         OGG:1268-1313, including the parity bumps of --ensure_nj_even.  ``sc_y0``: column 0 of the cap's latitudes, needed for

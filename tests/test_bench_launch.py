@@ -83,3 +83,14 @@ def test_self_launch_retries_once_when_the_port_was_taken(monkeypatch, capfd, tm
     monkeypatch.setattr(b, "self_launch_command", lambda n, argv, port: [sys.executable, "-c", always])
     assert b.self_launch(2, []) == 1
     assert "failed (exit code 1)" in capfd.readouterr()[1]
+
+
+def test_self_launch_timeout_keeps_the_ranks_stderr(monkeypatch, capfd):
+    """A run that hangs at N ranks: the children's stderr has been passed through as it came (a reader thread), so what they said before
+    they hung is on the terminal when the time limit kills them; exit code 124."""
+    b = _bench()
+    child = "import sys, time; sys.stderr.write('rank 1: waiting for the rendezvous\\n'); sys.stderr.flush(); time.sleep(60)"
+    monkeypatch.setattr(b, "self_launch_command", lambda n, argv, port: [sys.executable, "-c", child])
+    assert b.self_launch(2, [], timeout=3) == 124
+    out, err = capfd.readouterr()
+    assert out.strip() == "" and "waiting for the rendezvous" in err and "did not finish within 3 s" in err

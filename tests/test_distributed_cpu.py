@@ -205,3 +205,73 @@ def test_calibrated_split_is_broadcast_from_rank_0():
     lo, hi = sg_mod.Supergrid.rows_of(merc, 1, 2)
     assert abs((hi - lo) / merc.nj1 - 0.875 / 1.875) < 2.0 / merc.nj1
     assert sg_mod.Supergrid.rows_of(merc, 2, 3) != sg_mod.Supergrid.rows_of(merc, 1, 2)    # another world size: the model again
+
+
+def _refine_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ocean_model_grid_generator_amd.supergrid as sg_mod
+        plan = _plan(sg_mod, 2)
+        plan.set_split_times(6.0, 120.0, "test", top_capacity=(world, 0.9))
+        before = [sg_mod.Supergrid.rows_of(s, k, world) for s in plan.subs for k in range(world)]
+        # every rank "measures" its own share (no GPU here: a made-up time, the last rank 20 % slower) and the list is all-gathered
+        mine = 40.0 + rank if rank < world - 1 else 50.0
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        changed = plan.refine_split(gathered, world)
+        after = [sg_mod.Supergrid.rows_of(s, k, world) for s in plan.subs for k in range(world)]
+        q.put((rank, changed, before, after, plan.split_times["self_calibration"][-1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_rank_rebalances_the_split_from_the_gathered_times():
+    """Per-rank self-calibration (bench.py at N > 1): the ranks all-gather their own times per pass and each applies
+    SupergridPlan.refine_split to the same list -- the same new edges on every rank, the last rank's share scaled by
+    mean(others) / T_last, every row still covered once; inside the dead band nothing moves."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_refine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert all(r[1] for r in res) and res[0][2:] == res[1][2:] == res[2][2:]
+    rec = res[0][4]
+    assert rec["per_rank_us"] == [40.0, 41.0, 50.0] and rec["share_of_last_rank_before"] == 0.9
+    assert abs(rec["share_of_last_rank_after"] - 0.9 * 40.5 / 50.0) < 1e-12
+    import ocean_model_grid_generator_amd.supergrid as sg_mod
+    plan = _plan(sg_mod, 2)
+    plan.set_split_times(6.0, 120.0, "test", top_capacity=(3, 0.9))
+    merc = next(s for s in plan.subs if s.name == "Merc")
+    n_before = np.diff(sg_mod.Supergrid.rows_of(merc, 2, 3))[0]
+    assert plan.refine_split([40.0, 41.0, 50.0], 3)
+    n_after = np.diff(sg_mod.Supergrid.rows_of(merc, 2, 3))[0]
+    assert n_after < n_before
+    for s in plan.subs:
+        rows = []
+        for k in range(3):
+            lo, hi = sg_mod.Supergrid.rows_of(s, k, 3)
+            rows += list(range(lo, hi))
+        assert rows == list(range(s.nj1))
+    # the same at the world size of the node the bench is meant for: eight ranks, every row of every sub-grid of the 1/8 degree grid once
+    plan8 = _plan(sg_mod, 8)
+    plan8.set_split_times(6.5, 213.0, "test")
+    assert plan8.refine_split([31.0, 31.4, 31.2, 31.1, 31.3, 31.0, 31.2, 34.0], 8)
+    assert plan8.split_times["top_capacity"]["world"] == 8
+    for s in plan8.subs:
+        rows = []
+        for k in range(8):
+            lo, hi = sg_mod.Supergrid.rows_of(s, k, 8)
+            rows += list(range(lo, hi))
+        assert rows == list(range(s.nj1)), s.name
+    # within 3 %: the split stays (and the record says so)
+    assert not plan.refine_split([40.0, 41.0, 41.2], 3)
+    assert plan.split_times["self_calibration"][-1]["share_of_last_rank_after"] == plan.split_times["self_calibration"][-1]["share_of_last_rank_before"]
+    assert len(plan.split_times["self_calibration"]) == 2

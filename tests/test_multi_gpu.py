@@ -59,12 +59,14 @@ def test_two_ranks_reproduce_one_gpu_bitwise(extra):
     assert two["config"]["cells"] == one["config"]["cells"]
 
 
-@pytest.mark.parametrize("n,workload", [(2, "r2"), (4, "r4_om4")])
+@pytest.mark.parametrize("n,workload", [(2, "r2"), (4, "r4_om4"), (5, "r8")])
 def test_n_ranks_rehearsed_on_one_gpu(n, workload):
     """The whole N-rank run of bench.py on a box with ONE GPU (OGG_BENCH_ONE_GPU=1: every rank on cuda:0, the collectives over gloo
     because RCCL does not put two ranks on one device): the plain invocation starts its ranks, every rank takes its bands, barriers,
     the max-over-ranks reduction, the self-check's and the fingerprints' all-reduce, the gathered per-rank lines, ONE JSON line --
-    and the fingerprints of the band-sharded fields equal the single-GPU ones bit for bit."""
+    and the fingerprints of the band-sharded fields equal the single-GPU ones bit for bit.  (Five ranks is the most a one-GPU box of
+    this pool allows: six processes on the card, this one included; the 8-rank split itself is covered without processes in
+    tests/test_distributed_cpu.py and rehearsed share by share by scripts/rank_sweep.py.)"""
     one = _bench(1, ["--workload", workload, "--power-probe", "0"])
     many = _bench(n, ["--workload", workload, "--power-probe", "0"], {"OGG_BENCH_ONE_GPU": "1"})
     assert many["n_gpus"] == n and many["world_size"] == n and "rehearsal" in many
@@ -80,6 +82,11 @@ def test_n_ranks_rehearsed_on_one_gpu(n, workload):
     # the band split came from rank 0's own timings on this box, broadcast to the others
     bs = many["band_split"]
     assert bs and "measured by rank 0" in bs["source"] and 0 < bs["tail_us"] < bs["pass_us"]
+    # ... refined by every rank's own timing of its own share (all-gathered; one rebalancing step): the record holds every rank's time
+    sc = bs["self_calibration"]
+    assert len(sc) >= 1 and sc[0]["world"] == n and len(sc[0]["per_rank_us"]) == n and all(t > 0 for t in sc[0]["per_rank_us"])
+    assert bs["top_capacity"]["world"] == n and 0.3 <= bs["top_capacity"]["share_of_last_rank"] <= 1.3
+    assert len(many["per_rank"]) == n
     assert one["band_split"] is None or "fitted constants" in one["band_split"]["source"]
     assert many["self_check_metrics_error_percent"] and "error" not in many["self_check_metrics_error_percent"]
     for name, errs in many["self_check_metrics_error_percent"].items():
