@@ -429,19 +429,226 @@ def bq_group(pool, quick):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# round 5: the rows of the table that had no truth yet
+#   ax   OGG:719-729  angle_x over the EXACT mesh (bipolar: the pole row and the three rows under it; displaced pole: kept rows): what the
+#                     chain "mesh, then angle_x" returns without rounding anywhere.  The fp64 reference's distance from it is dominated by
+#                     the last-bit errors of its x, y, divided by the mesh spacing (5e-11 degrees at 1/8 degree; unbounded at the pole points)
+#   dm   OGG:447-467  displaced-pole mesh x, y on the three rows around r = r_pole and on two kept rows, every column
+#   bq11520           the bipolar quadrature at 1/16 degree: the four cells that touch a pole point + 200 regular cells
+#   mdso / mdsc       MIDAS metrics on the Southern Ocean and regular southern-cap sub-grids of the 1/8 degree grid
+# ---------------------------------------------------------------------------------------------------------------
+def angle_exact(xl, xr, yl, yr, yc):
+    """angle_x at an interior column from exact neighbours (degrees).  OGG:725."""
+    return mp.atan2(yr - yl, (xr - xl) * mp.cos(yc * PI180)) / PI180
+
+
+def ax_bp_point(args):
+    (Ni, Nj, lat0, lon_bp, rp), j, i, lon3, lat = args
+    pts = [bp_point((lo, lat, lon_bp, rp)) for lo in lon3]           # columns i-1, i, i+1 (fp64 inputs as the reference forms them)
+    x = [M(p[0][0]) + M(p[0][1]) for p in pts]
+    y = [M(p[1][0]) + M(p[1][1]) for p in pts]
+    if i == 0:
+        a = mp.atan2(y[2] - y[1], (x[2] - x[1]) * mp.cos(y[1] * PI180)) / PI180          # OGG:726
+    elif i == Ni:
+        a = mp.atan2(y[1] - y[0], (x[1] - x[0]) * mp.cos(y[1] * PI180)) / PI180          # OGG:727
+    else:
+        a = angle_exact(x[0], x[2], y[0], y[2], y[1])
+    return j, i, split(a)
+
+
+def ax_dp_point(args):
+    par, j, i, x64 = args                                            # x64: the oracle's unwrapped longitudes at i-1, i, i+1 (fixes the 360 k)
+    nx = par[0]
+    cap = Cap(*par)
+    x, y = [], []
+    for k, c in enumerate((i - 1, i, i + 1)):
+        c = min(max(c, 0), nx)
+        lam, phi = cap.project(M(float(c)), M(float(j)))
+        lam, phi = lam / PI180, phi / PI180
+        lam = lam + 360 * mp.nint((M(x64[k]) - lam) / 360)          # monotonic_bounding moves lam by multiples of 360 (OGG:470-475)
+        x.append(lam)
+        y.append(phi)
+    if i == 0:
+        a = mp.atan2(y[2] - y[1], (x[2] - x[1]) * mp.cos(y[1] * PI180)) / PI180
+    elif i == nx:
+        a = mp.atan2(y[1] - y[0], (x[1] - x[0]) * mp.cos(y[1] * PI180)) / PI180
+    else:
+        a = angle_exact(x[0], x[2], y[0], y[2], y[1])
+    return j, i, split(a), split(x[1]), split(y[1])
+
+
+def ax_group(pool, quick):
+    out = {}
+    # bipolar caps
+    for Ni, Nj, lat0 in ((5760, 960, 64.03160594077568), (11520, 1920, 64.04528618884338)):
+        lon_bp = -300.0
+        rp = float(np.tan(0.5 * (90 - lat0) * orc.PI_180))
+        lon_g = lon_bp + np.arange(Ni + 1) * 360.0 / float(Ni)
+        latg0 = lat0 + np.arange(Nj + 1) * (90 - lat0) / float(Nj)
+        q = Ni // 4
+        cols = sorted(set(list(range(0, Ni + 1, 64 if quick else 16)) + [c for m in (q, 3 * q) for c in range(m - 8, m + 9)] +
+                          [0, 1, Ni - 1, Ni, 2 * q - 1, 2 * q, 2 * q + 1]))
+        rows = [Nj - 3, Nj - 2, Nj - 1, Nj, Nj // 2]
+        par = (Ni, Nj, lat0, lon_bp, rp)
+        jobs = [(par, j, i, [lon_g[min(max(c, 0), Ni)] for c in (i - 1, i, i + 1)], latg0[j]) for j in rows for i in cols]
+        t0 = time.time()
+        res = pool.map(ax_bp_point, jobs, chunksize=16)
+        print("ax bp %d: %d points in %.0f s" % (Ni, len(jobs), time.time() - t0), flush=True)
+        tag = "axbp%d_" % Ni
+        jj, ii = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        t = np.array([r[2] for r in res])
+        x, y, _, _ = orc.generate_bipolar_cap_mesh(Ni, Nj, lat0, lon_bp, ensure_nj_even=False)
+        oa = orc.angle_x(x, y)[jj, ii]
+        err = np.abs((oa - t[:, 0]) - t[:, 1])
+        err = np.minimum(err, np.abs(err - 360.0))
+        near = (np.abs(ii - q) <= 8) | (np.abs(ii - 3 * q) <= 8)          # the columns around the two pole points
+        out.update({tag + "params": np.array([Ni, Nj, lat0, lon_bp, rp]), tag + "j": jj, tag + "i": ii, tag + "angle": t, tag + "near_pole_columns": near})
+        for nm, m in (("away", ~near), ("near", near & (jj < Nj)), ("poleline", near & (jj == Nj))):
+            out[tag + "eref_" + nm] = np.array(err[m].max())
+            print("ax bp %d oracle vs truth, %s: max %.3e deg, median %.3e" % (Ni, nm, err[m].max(), np.median(err[m])))
+    # displaced-pole caps (config 4 and OM4): kept rows
+    for tag, par, rows in (("axdp_", (5760, 560, -300.0, -78.0, 80.0, float(np.tan((90 - 85.85) * orc.PI_180) / np.tan(12.0 * orc.PI_180))),
+                            [276, 277, 300, 400, 500, 559, 560]),
+                           ("axdp4_", (2880, 280, -300.0, -78.0, 80.0, 0.2), [220, 221, 250, 279, 280])):
+        nx, ny = par[0], par[1]
+        cols = sorted(set(list(range(0, nx + 1, 176 if quick else 44)) + [0, 1, nx - 1, nx]))
+        x, y, _, _ = orc.generate_displaced_pole_grid(nx, ny, par[2], par[3], par[4], par[5])
+        jobs = [(par, j, i, [x[j, min(max(c, 0), nx)] for c in (i - 1, i, i + 1)]) for j in rows for i in cols]
+        t0 = time.time()
+        res = pool.map(ax_dp_point, jobs, chunksize=16)
+        print("ax %s: %d points in %.0f s" % (tag, len(jobs), time.time() - t0), flush=True)
+        jj, ii = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        t = np.array([r[2] for r in res])
+        oa = orc.angle_x(x, y)[jj, ii]
+        err = np.abs((oa - t[:, 0]) - t[:, 1])
+        err = np.minimum(err, np.abs(err - 360.0))
+        out.update({tag + "params": np.array(par), tag + "j": jj, tag + "i": ii, tag + "angle": t, tag + "eref": np.array(err.max())})
+        print("ax %s oracle vs truth: max %.3e deg, median %.3e" % (tag, err.max(), np.median(err)))
+    return out
+
+
+def dm_row(args):
+    par, j, cols, x64 = args
+    cap = Cap(*par)
+    out = []
+    for i, xo in zip(cols, x64):
+        lam, phi = cap.project(M(float(i)), M(float(j)))
+        lam, phi = lam / PI180, phi / PI180
+        lam = lam + 360 * mp.nint((M(xo) - lam) / 360)
+        out.append([split(lam), split(phi)])
+    return out
+
+
+def dm_group(pool, quick):
+    out = {}
+    for tag, par in (("dm_", (5760, 560, -300.0, -78.0, 80.0, float(np.tan((90 - 85.85) * orc.PI_180) / np.tan(12.0 * orc.PI_180)))),
+                     ("dm4_", (2880, 280, -300.0, -78.0, 80.0, 0.2))):
+        nx, ny, lon0, lat0, lon_dp, r_dp = par
+        jpole = float(np.arctan(r_dp * np.tan(12.0 * orc.PI_180)) / orc.PI_180 / (12.0 / ny))      # the row where r = r_pole
+        rows = [int(jpole) - 1, int(jpole), int(jpole) + 1] + ([276, 559] if nx == 5760 else [220, 279])
+        cols = np.arange(0, nx + 1, 64 if quick else 1)
+        x, y, _, _ = orc.generate_displaced_pole_grid(nx, ny, lon0, lat0, lon_dp, r_dp)
+        chunks = np.array_split(cols, 64)
+        jobs = [(par, j, c, x[j, c]) for j in rows for c in chunks]
+        t0 = time.time()
+        res = pool.map(dm_row, jobs, chunksize=1)
+        print("dm %s: %d points in %.0f s" % (tag, len(rows) * cols.size, time.time() - t0), flush=True)
+        t = np.array([p for r in res for p in r]).reshape(len(rows), cols.size, 2, 2)
+        out.update({tag + "params": np.array(par), tag + "rows": np.array(rows), tag + "cols": cols, tag + "x": t[:, :, 0, :].copy(), tag + "y": t[:, :, 1, :].copy(),
+                    tag + "jpole": np.array(jpole)})
+        for f, o, k in (("x", x, 0), ("y", y, 1)):
+            v = o[rows][:, cols]
+            err = np.abs((v - t[:, :, k, 0]) - t[:, :, k, 1])
+            out[tag + f + "_eref_polar_rows"] = np.array(err[:3].max())
+            out[tag + f + "_eref_kept_rows"] = np.array(err[3:].max())
+            print("dm %s oracle vs truth %s: rows around r_pole %.3e deg, kept rows %.3e deg" % (tag, f, err[:3].max(), err[3:].max()))
+    return out
+
+
+def bq16_group(pool, quick):
+    Ni, Nj, lat0, lon_bp = 11520, 1920, 64.04528618884338, -300.0
+    rp = float(np.tan(0.5 * (90 - lat0) * orc.PI_180))
+    q = Ni // 4
+    cells = [(Nj - 1, c) for c in (q - 1, q, 3 * q - 1, 3 * q)]
+    rng = np.random.default_rng(11)
+    rows = [0, 1, 480, 960, 1440, 1780, 1800, 1880, 1910, 1917]
+    for j in rows:
+        cells += [(j, int(c)) for c in rng.integers(0, Ni, 6 if quick else 20)]
+    nodes = orc._lattice_1d(Nj, 5).reshape(Nj + 1, 5)
+    nodes[:, -1] = np.where(nodes[:, -1] == Nj, Nj - 0.001, nodes[:, -1])
+    i1d = orc._lattice_1d(Ni, 5).reshape(Ni + 1, 5)
+    par = (Ni, Nj, lat0, lon_bp, rp)
+    t0 = time.time()
+    res = pool.map(bq_cell, [(par, j, i, nodes[j], i1d[i]) for j, i in cells], chunksize=4)
+    print("bq 11520: %d cells in %.0f s" % (len(cells), time.time() - t0), flush=True)
+    tag = "bq11520_"
+    jj, ii = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    vals = np.array([r[2] for r in res])
+    out = {tag + "params": np.array([Ni, Nj, lat0, lon_bp, rp]), tag + "j": jj, tag + "i": ii}
+    o = [np.zeros(jj.size) for _ in range(3)]
+    for j in sorted(set(jj.tolist())):
+        r = orc.bipolar_cap_metrics_quad_fast(5, Ni, Nj, lat0, lon_bp, rp, j_first=j, j_last=j + 1)
+        m = jj == j
+        for k in range(3):
+            o[k][m] = r[k][j, ii[m]]
+    pole = (jj == Nj - 1) & np.isin(ii, (q - 1, q, 3 * q - 1, 3 * q))
+    edge = ((np.abs(ii - q) <= 6) | (np.abs(ii - 3 * q) <= 6) | (np.abs(ii - Ni // 2) <= 1) | (ii <= 1) | (ii >= Ni - 2)) & ~pole
+    out[tag + "pole_cells"], out[tag + "edge_cells"] = pole, edge
+    for k, f in enumerate(("dx", "dy", "area")):
+        t = vals[:, k, :]
+        out[tag + f] = t.copy()
+        err = np.abs((o[k] - t[:, 0]) - t[:, 1]) / np.abs(t[:, 0])
+        for nm, m in (("", ~pole & ~edge), ("_polecells", pole)):
+            out[tag + f + "_eref_rel" + nm] = np.array(err[m].max())
+            print("bq 11520 oracle vs truth %s%s: rel %.3e" % (f, nm, err[m].max()))
+    return out
+
+
+def mdso_group(pool, quick):
+    """MIDAS on the Southern Ocean sub-grid and the regular southern cap of the 1/8 degree grid (axes as main() forms them, OGG:1080-1157)."""
+    out = {}
+    Ni = 5760
+    phiM = orc.generate_mercator_grid(Ni, -66.85954725, 64.05895973, -300.0, 360, 8.0, True, False)[1][:, 0]
+    latUp = float(phiM[0])
+    xso, yso = orc.generate_latlon_grid(Ni, 440, -300.0, 360.0, -78.0, latUp + 78.0, ensure_nj_even=False)
+    xsc, ysc = orc.generate_latlon_grid(Ni, 192, -300.0, 360.0, -90.0, 12.0, ensure_nj_even=False)
+    for tag, x, y in (("mdso_", xso, yso), ("mdsc_", xsc, ysc)):
+        xa, ya = x[0].copy(), y[:, 0].copy()
+        cols = np.array([0, 1, Ni // 4 - 1, Ni // 4, Ni // 2 - 1, Ni // 2, 3 * Ni // 4 + 1, Ni - 2, Ni - 1])
+        rows = np.arange(0, ya.size - 1, 20 if quick else 1)
+        res = np.array(pool.map(md_rows, [(np.stack([xa[cols], xa[cols + 1]], 1), ya[j:j + 2]) for j in rows], chunksize=16))
+        out.update({tag + "xaxis": xa, tag + "yaxis": ya, tag + "cols": cols, tag + "rows": rows})
+        odx, ody, oar = orc.generate_grid_metrics_MIDAS(np.tile(xa, (ya.size, 1)), np.tile(ya[:, None], (1, xa.size)))
+        for k, (f, o) in enumerate((("dx", odx), ("dy", ody), ("area", oar))):
+            t = res[:, :, k, :]
+            out[tag + f] = t.copy()
+            v = o[rows][:, cols]
+            nz = np.abs(t[..., 0]) > 1e-6 * np.abs(t[..., 0]).max()         # dx on the pole row of the cap (cos(-90 degrees) ~ 6e-17): absolute only
+            err = np.abs((v - t[..., 0]) - t[..., 1])
+            out[tag + f + "_eref_abs"] = np.array(err.max())
+            out[tag + f + "_eref_rel"] = np.array((err[nz] / np.abs(t[..., 0][nz])).max())
+            print("%s oracle vs truth %s: abs %.3e rel %.3e" % (tag, f, err.max(), out[tag + f + "_eref_rel"]))
+    return out
+
+
+GROUPS = {"md": md_group, "bq": bq_group, "bp": bp_group, "dp": dp_group, "dp4": lambda pool, quick: dp_group(pool, quick, "dp4"),
+          "ax": ax_group, "dm": dm_group, "bq16": bq16_group, "mdso": mdso_group}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--groups", nargs="+", default=list(GROUPS), help="which groups to (re)compute; the others are kept from the existing fixture")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="a thin sample (smoke run of this script; does not overwrite the fixture)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "truth_table.npz"))
     a = ap.parse_args()
     out = {"dps": np.array(mp.mp.dps)}
+    if not a.quick and os.path.exists(a.out) and set(a.groups) != set(GROUPS):
+        out.update({k: v for k, v in np.load(a.out).items()})              # keep the groups that are not recomputed
     with Pool(a.procs) as pool:
-        out.update(md_group(pool, a.quick))
-        out.update(bq_group(pool, a.quick))
-        out.update(bp_group(pool, a.quick))
-        out.update(dp_group(pool, a.quick))
-        out.update(dp_group(pool, a.quick, "dp4"))
+        for g in a.groups:
+            out.update(GROUPS[g](pool, a.quick))
     path = a.out if not a.quick else "/tmp/truth_table_quick.npz"
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -256,3 +256,145 @@ def test_bipolar_quadrature_vs_truth(ogg, truth, monkeypatch, guard_k, sym):
     assert rep["regular_cells/area"]["hip_vs_truth"]["max_abs"] <= K_REF * float(truth[tag + "area_eref_abs"])
     assert rep["regular_cells/area"]["hip_vs_oracle"]["max_abs"] < 1e-6
     assert float(truth[tag + "area_eref_abs_polecells"]) > 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 5: the rows of the table that had no truth yet (scripts/truth_table.py groups ax, dm, bq16, mdso)
+# ---------------------------------------------------------------------------------------------------------------
+def _pass_fields(flags, sym):
+    """The fused pass of a whole grid on one GPU: {sub-grid name: {field: host array}} (what main() produces)."""
+    from ocean_model_grid_generator_amd import supergrid
+    plan = supergrid.SupergridPlan(cap_symmetry=sym, **flags)
+    g = supergrid.Supergrid(plan, rank=0, world=1, device="cuda:0", halo="recompute")
+    g.step()
+    out = g.bands_to_host()
+    g.close()
+    return plan, out
+
+
+def _adiff(a, t):
+    e = err(a, t)
+    return np.minimum(e, np.abs(e - 360.0))
+
+
+@pytest.mark.parametrize("sym", SYMS)
+@pytest.mark.parametrize("r", [8.0, 16.0])
+def test_bipolar_angle_vs_truth(ogg, truth, r, sym):
+    """angle_x (OGG:719-729) of the bipolar cap as the PASS produces it (fused into the mesh kernel: neighbours from wave shuffles, cos phi
+    taken algebraically) against angle_x over the EXACT mesh, on the pole row, the three rows under it and a mid-cap row.  The fp64
+    reference's own distance from that truth is set by the last-bit errors of its x, y over the mesh spacing: 2.6e-11 degrees (1/8 degree)
+    away from the pole points, 8e-10 within 8 columns of them, and unbounded (6 degrees) on the pole row next to the pole points -- where the
+    field is noise in the reference too and nothing is asserted."""
+    Ni = int(r * 720)
+    tag = "axbp%d_" % Ni
+    jj, ii, near = truth[tag + "j"], truth[tag + "i"], truth[tag + "near_pole_columns"]
+    Nj = int(truth[tag + "params"][1])
+    plan, f = _pass_fields(dict(inverse_resolution=r), sym)
+    bp = next(s for s in plan.subs if s.name == "BP")
+    assert bp.Nj == Nj and abs(bp.lat0_bp - float(truth[tag + "params"][2])) < 1e-12
+    got = f["BP"]["angle_dx"][jj, ii]
+    e = _adiff(got, truth[tag + "angle"])
+    rep = {}
+    for nm, m in (("away", ~near), ("near", near & (jj < Nj)), ("poleline", near & (jj == Nj))):
+        eref = float(truth[tag + "eref_" + nm])
+        rep[nm] = {"oracle_vs_truth_deg": eref, "hip_vs_truth_deg": float(e[m].max()), "hip_vs_truth_median_deg": float(np.median(e[m])), "n": int(m.sum())}
+    REPORT["angle_x_OGG719_729/bipolar_Ni%d%s" % (Ni, "" if sym else "_every_column")] = rep
+    _save()
+    for nm in ("away", "near"):
+        assert rep[nm]["hip_vs_truth_deg"] <= K_REF * rep[nm]["oracle_vs_truth_deg"], (nm, rep[nm])
+
+
+@pytest.mark.parametrize("tag,flags", [("axdp_", dict(inverse_resolution=8.0, lon_dp=80.0, lat_dp=-85.85)),
+                                       ("axdp4_", dict(inverse_resolution=4.0, r_dp=0.2))])
+def test_displaced_pole_angle_and_mesh_vs_truth(ogg, truth, tag, flags):
+    """angle_x of the displaced-pole cap's kept rows from the pass (dpole_mesh_kernel: projection, unwrap by look-back and angle in one
+    launch) against angle_x over the exact mesh; and the mesh itself (OGG:447-467) on every column of two kept rows."""
+    jj, ii = truth[tag + "j"], truth[tag + "i"]
+    plan, f = _pass_fields(flags, True)
+    sc = plan.subs[0]
+    assert sc.kind == "dpole" and abs(sc.r_dp - float(truth[tag + "params"][5])) < 1e-15
+    keep = (jj >= sc.row0) & (jj < sc.row0 + sc.nj1)
+    got = f["SC"]["angle_dx"][jj[keep] - sc.row0, ii[keep]]
+    e = _adiff(got, truth[tag + "angle"][keep])
+    eref = float(truth[tag + "eref"])
+    rep = {"angle": {"oracle_vs_truth_deg": eref, "hip_vs_truth_deg": float(e.max()), "n": int(keep.sum())}}
+    dm = "dm_" if tag == "axdp_" else "dm4_"
+    rows, cols = truth[dm + "rows"], truth[dm + "cols"]
+    for k, row in enumerate(rows):
+        if not (sc.row0 <= row < sc.row0 + sc.nj1):
+            continue
+        for fld, key in (("x", "x"), ("y", "y")):
+            ex = err(f["SC"][fld][row - sc.row0, cols], truth[dm + key][k])
+            rr = rep.setdefault("mesh_" + fld, {"oracle_vs_truth_deg": float(truth[dm + key + "_eref_kept_rows"]), "hip_vs_truth_deg": 0.0})
+            rr["hip_vs_truth_deg"] = max(rr["hip_vs_truth_deg"], float(ex.max()))
+    REPORT["displaced_pole_mesh_and_angle/%s" % tag.rstrip("_")] = rep
+    _save()
+    assert rep["angle"]["hip_vs_truth_deg"] <= K_REF * eref, rep
+    for fld in ("x", "y"):
+        assert rep["mesh_" + fld]["hip_vs_truth_deg"] <= K_REF * max(rep["mesh_" + fld]["oracle_vs_truth_deg"], 3e-14), rep   # (floor: one ulp of 300 degrees / 2)
+
+
+@pytest.mark.parametrize("tag", ["dm_", "dm4_"])
+def test_displaced_pole_mesh_around_r_pole_vs_truth(ogg, truth, tag):
+    """The displaced-pole mesh (OGG:447-467 + the unwrap, OGG:470-475) on the three rows around r = r_pole -- where the longitude swings by
+    180 degrees between two columns; main() discards them -- and two kept rows, every column, from the function-level entry point."""
+    nx, ny, lon0, lat0, lon_dp, r_dp = truth[tag + "params"]
+    nx, ny = int(nx), int(ny)
+    x, y, _, _ = ogg.generate_displaced_pole_grid(nx, ny, float(lon0), float(lat0), float(lon_dp), float(r_dp))
+    rows, cols = truth[tag + "rows"], truth[tag + "cols"]
+    rep = {}
+    for fld, a in (("x", x), ("y", y)):
+        e = err(a[rows][:, cols], truth[tag + fld])
+        # a point whose unwrap state differs from the oracle's is 360 degrees off: none may be (the bit-level test of the unwrap is in
+        # tests/test_gpu_parity.py; here the TRUTH was unwrapped with the oracle's states)
+        assert e.max() < 1.0
+        rep[fld] = {"rows_around_r_pole": {"oracle_vs_truth_deg": float(truth[tag + fld + "_eref_polar_rows"]), "hip_vs_truth_deg": float(e[:3].max())},
+                    "kept_rows": {"oracle_vs_truth_deg": float(truth[tag + fld + "_eref_kept_rows"]), "hip_vs_truth_deg": float(e[3:].max())}}
+    REPORT["displaced_pole_mesh_OGG447_467/%s" % tag.rstrip("_")] = rep
+    _save()
+    for fld in ("x", "y"):
+        for grp in ("rows_around_r_pole", "kept_rows"):
+            r = rep[fld][grp]
+            assert r["hip_vs_truth_deg"] <= K_REF * max(r["oracle_vs_truth_deg"], 3e-14), (fld, grp, r)
+
+
+@pytest.mark.parametrize("sym", SYMS)
+def test_bipolar_quadrature_r16_vs_truth(ogg, truth, sym):
+    """The bipolar quadrature at 1/16 degree (round 4 had 1/8 degree only): the four cells that touch a pole point + 200 regular cells."""
+    tag = "bq11520_"
+    Ni, Nj, lat0, lon_bp, rp = truth[tag + "params"]
+    Ni, Nj = int(Ni), int(Nj)
+    jj, ii, pole, edge = truth[tag + "j"], truth[tag + "i"], truth[tag + "pole_cells"], truth[tag + "edge_cells"]
+    got = ogg.bipolar_cap_metrics_quad_fast(5, Ni, Nj, float(lat0), float(lon_bp), float(rp), symmetry=sym)
+    rep = {}
+    for k, f in enumerate(("dx", "dy", "area")):
+        t = truth[tag + f]
+        e = err(got[k][jj, ii], t) / np.abs(t[:, 0])
+        for nm, m, sfx in (("regular_cells", ~pole & ~edge, ""), ("the_four_cells_that_touch_a_pole_point", pole, "_polecells")):
+            eref = float(truth[tag + f + "_eref_rel" + sfx])
+            rep["%s/%s" % (nm, f)] = {"oracle_vs_truth": eref, "hip_vs_truth": float(e[m].max()), "n": int(m.sum())}
+            assert e[m].max() <= K_REF * max(eref, 2e-14), (f, nm, rep["%s/%s" % (nm, f)])
+    REPORT["bipolar_quadrature_OGG125_188/Ni11520%s" % ("" if sym else "_every_column")] = rep
+    _save()
+
+
+@pytest.mark.parametrize("tag", ["mdso_", "mdsc_"])
+def test_midas_southern_subgrids_vs_truth(ogg, truth, tag):
+    """MIDAS metrics (OGG:695-713) on the Southern Ocean sub-grid and the regular southern cap of the 1/8 degree grid (round 4: Mercator only),
+    through the fused lat-lon kernel of the pass -- what main() runs."""
+    plan, f = _pass_fields(dict(inverse_resolution=8.0), True)
+    name = "SO" if tag == "mdso_" else "SC"
+    ya, cols, rows = truth[tag + "yaxis"], truth[tag + "cols"], truth[tag + "rows"]
+    assert f[name]["y"].shape[0] == ya.size and np.abs(f[name]["y"][:, 0] - ya).max() < 1e-13
+    rep = {}
+    for fld in ("dx", "dy", "area"):
+        t = truth[tag + fld]
+        vh = f[name][fld][rows][:, cols]
+        e = err(vh, t)
+        nz = np.abs(t[..., 0]) > 1e-6 * np.abs(t[..., 0]).max()
+        rep[fld] = {"oracle_vs_truth_rel": float(truth[tag + fld + "_eref_rel"]), "hip_vs_truth_rel": float((e[nz] / np.abs(t[..., 0][nz])).max()),
+                    "oracle_vs_truth_abs": float(truth[tag + fld + "_eref_abs"]), "hip_vs_truth_abs": float(e.max())}
+        assert rep[fld]["hip_vs_truth_rel"] <= K_REF * max(rep[fld]["oracle_vs_truth_rel"], 2.3e-16), (fld, rep[fld])
+        assert rep[fld]["hip_vs_truth_abs"] <= K_REF * max(rep[fld]["oracle_vs_truth_abs"], 1e-12), (fld, rep[fld])
+    REPORT["midas_OGG695_713/%s_Ni5760" % name] = rep
+    _save()

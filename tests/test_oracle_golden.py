@@ -220,3 +220,45 @@ def test_truth_table_bipolar_quadrature_rows():
                 if sel.any():
                     assert (e[sel] / np.abs(t[sel, 0])).max() <= 2.0 * float(T[tag + f + "_eref_rel" + sfx]) + 1e-16, (j, f, sfx)
     assert 1e-6 < float(T[tag + "area_eref_abs"]) < 1e-5 and 1e-3 < float(T[tag + "area_eref_abs_polecells"]) < 1.0
+
+
+def test_truth_table_round5_groups():
+    """The groups added in round 5 (scripts/truth_table.py --groups ax dm bq16 mdso): the oracle reproduces the distances from the truth
+    recorded in the fixture, and those distances are what DESIGN.md quotes -- angle_x over the exact mesh: 2.6e-11 degrees (1/8 degree) away
+    from the pole points, 8e-10 within 8 columns of them, degrees ON the pole row next to them; the displaced-pole mesh: 1e-13 degrees on
+    kept rows, 4e-12 / 2.6e-11 around r = r_pole; the 1/16 degree bipolar quadrature: 1.2e-7 (area) in the four pole cells."""
+    T = np.load(os.path.join(GOLD, "truth_table.npz"))
+    for Ni in (5760, 11520):
+        tag = "axbp%d_" % Ni
+        _, Nj, lat0, lon_bp, rp = T[tag + "params"]
+        Nj = int(Nj)
+        jj, ii, near = T[tag + "j"], T[tag + "i"], T[tag + "near_pole_columns"]
+        x, y, _, _ = orc.generate_bipolar_cap_mesh(Ni, Nj, float(lat0), float(lon_bp), ensure_nj_even=False)
+        rows = np.unique(jj)
+        a = np.zeros(jj.size)
+        for j in rows:
+            lo = max(j - 0, 0)
+            m = jj == j
+            a[m] = orc.angle_x(x[lo:lo + 1], y[lo:lo + 1])[0, ii[m]]
+        e = _err(a, T[tag + "angle"])
+        e = np.minimum(e, np.abs(e - 360.0))
+        assert e[~near].max() <= 2.0 * float(T[tag + "eref_away"]) and e[near & (jj < Nj)].max() <= 2.0 * float(T[tag + "eref_near"])
+        assert float(T[tag + "eref_away"]) < 1e-10 and float(T[tag + "eref_near"]) < 5e-9 and float(T[tag + "eref_poleline"]) > 1.0
+    for tag, eref_max in (("axdp_", 2e-10), ("axdp4_", 1e-10)):
+        nx, ny, lon0, lat0, lon_dp, r_dp = T[tag + "params"]
+        x, y, _, _ = orc.generate_displaced_pole_grid(int(nx), int(ny), lon0, lat0, lon_dp, r_dp)
+        e = _err(orc.angle_x(x, y)[T[tag + "j"], T[tag + "i"]], T[tag + "angle"])
+        e = np.minimum(e, np.abs(e - 360.0))
+        assert e.max() <= 2.0 * float(T[tag + "eref"]) and float(T[tag + "eref"]) < eref_max
+        dm = "dm_" if tag == "axdp_" else "dm4_"
+        rows, cols = T[dm + "rows"], T[dm + "cols"]
+        assert cols.size == int(nx) + 1 and rows.size == 5
+        for fld, o in (("x", x), ("y", y)):
+            e = _err(o[rows][:, cols], T[dm + fld])
+            assert e[:3].max() <= 2.0 * float(T[dm + fld + "_eref_polar_rows"]) and e[3:].max() <= 2.0 * float(T[dm + fld + "_eref_kept_rows"])
+        assert float(T[dm + "x_eref_kept_rows"]) < 2e-13 and float(T[dm + "y_eref_kept_rows"]) < 5e-14 and float(T[dm + "x_eref_polar_rows"]) < 1e-10
+    tag = "bq11520_"
+    assert T[tag + "pole_cells"].sum() == 4 and (~T[tag + "pole_cells"] & ~T[tag + "edge_cells"]).sum() >= 190
+    assert 1e-8 < float(T[tag + "area_eref_rel_polecells"]) < 1e-6 and float(T[tag + "area_eref_rel"]) < 2e-12
+    for tag in ("mdso_", "mdsc_"):
+        assert float(T[tag + "dx_eref_rel"]) < 1e-13 and float(T[tag + "dy_eref_rel"]) < 1e-15 and 1e-6 < float(T[tag + "area_eref_abs"]) < 5e-5
