@@ -178,10 +178,10 @@ def valu_bound_roofline(hbm_roof, valu, launch_ms):
             "source": valu.get("source")}
 
 
-def time_other_arc(supergrid, plan_flags, arc, device, steps, torch):
+def time_other_arc(supergrid, plan_flags, arc, device, steps, torch, cap_symmetry=None):
     """ms per pass of the same workload with the OTHER arc form of the displaced-pole quadrature (a second set of band buffers; after the
     timed region)."""
-    plan = supergrid.SupergridPlan(dp_arc=arc, **plan_flags)
+    plan = supergrid.SupergridPlan(dp_arc=arc, cap_symmetry=cap_symmetry, **plan_flags)
     sg = supergrid.Supergrid(plan, rank=0, world=1, device=device, halo="recompute")
     sg.launch, sg.overlap = "pass", False
     for _ in range(30):
@@ -365,6 +365,10 @@ def main():
                          "than the fp64 reference itself (profiles/r04_truth_table.json; `parity`).  The other form is timed after the timed "
                          "region and reported as `dp_arc_other` (--dp-arc-other 0: skip)")
     ap.add_argument("--dp-arc-other", type=int, default=1)
+    ap.add_argument("--cap-symmetry", default="mirror", choices=["mirror", "none"],
+                    help="mirror (default, what main() runs): the bipolar cap from a quarter of its columns, the displaced-pole quadrature from "
+                         "half of them, written to their mirror images (DESIGN.md 2: as far from the exact value of the reference's formula as "
+                         "the reference's own columns); none: every column evaluated, as the reference does (rounds 1-4)")
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
                     help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
                          "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
@@ -400,7 +404,7 @@ def main():
     from ocean_model_grid_generator_amd import _lib, supergrid
 
     flags = WORKLOADS[args.workload]
-    plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **flags)
+    plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, cap_symmetry=(args.cap_symmetry == "mirror"), **flags)
     # band split: the last rank's share follows from two timings (the fix-up launch only it runs, a whole pass) that rank 0 takes on
     # THIS box before any band exists and broadcasts (OGG_SPLIT_CALIBRATE=0: the fitted constants of rounds 2-3)
     if os.environ.get("OGG_SPLIT_CALIBRATE", "1") != "0":
@@ -606,7 +610,8 @@ def main():
     dp_other = None
     if has_dp and args.dp_arc_other and world == 1 and args.as_rank is None and args.latlon == "fused":
         try:
-            dp_other = time_other_arc(supergrid, flags, "chord" if args.dp_arc == "literal" else "literal", device, args.steps, torch)
+            dp_other = time_other_arc(supergrid, flags, "chord" if args.dp_arc == "literal" else "literal", device, args.steps, torch,
+                                      cap_symmetry=(args.cap_symmetry == "mirror"))
         except Exception as exc:  # never lose the bench line over the secondary number
             dp_other = {"error": repr(exc)}
     power = None
@@ -652,8 +657,9 @@ def main():
             counters_note[fname] = {"key": key, "collected_with_src_hash": h, "quoted": bool(rec) and h == lib_hash}
             return rec if (rec and h == lib_hash) else {}
 
-        pmc = committed("hbm_traffic.json", args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else ""))
-        valu = committed("valu_counters.json", args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else ""))
+        ckey = args.workload + (" --dp-arc literal" if (has_dp and args.dp_arc == "literal") else "") + (" --cap-symmetry none" if args.cap_symmetry == "none" else "")
+        pmc = committed("hbm_traffic.json", ckey)
+        valu = committed("valu_counters.json", ckey)
         roof_valu = None
         if launches:  # the launches of the fused pass, timed inside the timed region
             n_sampled = launches.pop("sampled_passes")
@@ -730,7 +736,7 @@ def main():
             "band_split": plan.split_times,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
-                       "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
+                       "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "cap_symmetry": args.cap_symmetry, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
                        "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
                            world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
             "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned,
