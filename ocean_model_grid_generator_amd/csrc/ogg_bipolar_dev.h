@@ -487,46 +487,79 @@ struct QuadParams {
     double sx, sy, rp2p, rp2m, rp2x4, cdx, guard_kk;
 };
 
-// The columns a grid of strip workgroups walks, as ONE compact index space of up to three runs of consecutive cells, each closed by the
-// node column behind its last cell (a "closing" entry: it feeds dyq only).  Without symmetry there is one run, the cells 0 .. nx-1
-// closed by column nx.  With it (QuadCols::sym): the projection is mirror-symmetric about its two pole meridians (lattice columns
-// nx/4, 3nx/4) and about the fold lines (columns 0, nx/2) -- sinla and alpha2 (OGG:42-45) are functions of min(d, 360 - d) and of
-// sin / cos^2 of it --, so the cells [0, nx/4) determine the whole row: a lane that owns cell i >= z also writes its values to the
-// cells nx/2-1-i, nx/2+i, nx-1-i (dyq, on node columns: i > z to nx/2-i, nx/2+i, nx-i).  The reference evaluates every column with
-// its own roundings (lon_bp + i 360/Ni is rounded at magnitude 300 at one end of the row and at 60 at the other), and its own results
-// are mirror images of each other only to ~5.7e-14 degrees / (distance from the fold line): the z cells next to each fold line
-// (plan_quad: 6 degrees of longitude, where the reference's own asymmetry has fallen to 7e-15 relative in area, 3e-15 in dx, 5e-15 in
-// dy at 1/8 and 1/16 degree) are therefore evaluated at their own columns: run 1 = cells [nx/2-z, nx/2+z), run 2 =
-// [nx-z, nx), and the cells [0, z) of run 0 have no images.
+// The columns a grid of strip workgroups walks: up to three RUNS of consecutive cells, each a whole number of workgroups (QS_WAVES
+// strips of QS_CELLS cells; the node column behind the last cell of a run -- it feeds dyq only -- is the halo lane of the run's last
+// strip).  Without symmetry there is one run, the cells 0 .. nx-1.  With it (QuadCols::sym): the projection is mirror-symmetric about
+// its two pole meridians (lattice columns nx/4, 3nx/4) and about the fold lines (columns 0, nx/2) -- sinla and alpha2 (OGG:42-45) are
+// functions of min(d, 360 - d) and of sin / cos^2 of it --, so the cells [0, nx/4) determine the whole row: a lane that owns cell
+// i >= z also writes its values to the cells nx/2-1-i, nx/2+i, nx-1-i (dyq, on node columns: i > z to nx/2-i, nx/2+i, nx-i).  The
+// reference evaluates every column with its own roundings (lon_bp + i 360/Ni is rounded at magnitude 300 at one end of the row and
+// at 60 at the other), and its own results are mirror images of each other only to ~5.7e-14 degrees / (distance from the fold line):
+// the z cells next to each fold line (plan_quad: 6 degrees of longitude, where the reference's own asymmetry has fallen to 7e-15
+// relative in area, 3e-15 in dx, 5e-15 in dy at 1/8 and 1/16 degree) are therefore evaluated at their own columns: run 1 =
+// cells [nx/2-z, nx/2+z), run 2 = [nx-z, nx), and the cells [0, z) of run 0 have no images.
+constexpr int QS_CELLS = 63;   // cells per wave strip (lane 63: the halo lane, the first cell of the next strip)
+constexpr int QS_WAVES = 4;    // strips per workgroup
+constexpr int QS_WG_CELLS = QS_CELLS * QS_WAVES;   // 252 cells = 2016 bytes of a row of one field per workgroup
+
 struct QuadCols {
-    long r1, r2, total;   // compact entries of run 0: [0, r1), run 1: [r1, r2), run 2: [r2, total); the last entry of a run is its closing column
-    long lo1, lo2;        // first cell of run 1, of run 2 (run 0 starts at cell 0)
+    long lo[3], hi[3];    // run r: cells [lo, hi), closed by node column hi
+    long g_end[3];        // workgroups (along the columns) of runs 0 .. r
     long z;               // sym: cells [0, z) of run 0 (columns [0, z]) have no images
     int sym;
 };
 
-// what lane `lane` of strip `strip` owns in the column space `cs`
+// what lane `lane` of wave `wave` of column workgroup `wg` owns in the column space `cs`
 struct QuadLane {
     long ci;          // its cell = its node column (the cell's left edge)
-    bool active;      // the strip exists (wave-uniform)
-    bool col_lane;    // writes dyq at node column ci ...
-    bool cell_lane;   // ... and dxq, daq of cell ci
-    bool img_cell;    // and the three mirror images of the cell: cells nx/2-1-ci, nx/2+ci, nx-1-ci
-    bool img_col;     // of the node column: columns nx/2-ci, nx/2+ci, nx-ci
+    long c0;          // first cell of the workgroup
+    int nv;           // cells of the workgroup inside its run (0 .. QS_WG_CELLS); workgroup-uniform
+    int run;
+    bool active;      // the wave has cells (wave-uniform)
+    bool cell_lane;   // owns dxq, daq of cell ci and dyq of node column ci
+    bool closing;     // the node column behind the run's last cell: dyq only (the halo lane of the run's last strip)
+    bool img_cell;    // the cell also goes to its three mirror images: cells nx/2-1-ci, nx/2+ci, nx-1-ci
+    bool img_col;     // the node column to its images: columns nx/2-ci, nx/2+ci, nx-ci
 };
 
-OGG_HD QuadLane quad_lane(const QuadCols& cs, long strip, int lane, int cells_per_strip) {
+OGG_HD QuadLane quad_lane(const QuadCols& cs, long wg, int wave, int lane) {
     QuadLane q{};
-    q.active = strip * cells_per_strip < cs.total;
-    const long ke = strip * cells_per_strip + lane;   // compact entry of this lane; the last lane of a wave: the first entry of the next strip
-    const long kk = ke < cs.total ? ke : cs.total - 1;
-    q.ci = kk < cs.r1 ? kk : (kk < cs.r2 ? cs.lo1 + (kk - cs.r1) : cs.lo2 + (kk - cs.r2));
-    const bool closing = (kk == cs.r1 - 1) || (kk == cs.r2 - 1) || (kk == cs.total - 1);
-    q.col_lane = q.active && (lane < cells_per_strip) && (ke < cs.total);
-    q.cell_lane = q.col_lane && !closing;
-    q.img_cell = cs.sym && q.cell_lane && kk < cs.r1 && q.ci >= cs.z;
-    q.img_col = cs.sym && q.col_lane && kk < cs.r1 && q.ci > cs.z;
+    q.run = (wg < cs.g_end[0]) ? 0 : ((wg < cs.g_end[1]) ? 1 : 2);
+    const long g0 = (q.run == 0) ? 0 : cs.g_end[q.run - 1];
+    const long lo = cs.lo[q.run], hi = cs.hi[q.run];
+    q.c0 = lo + (wg - g0) * QS_WG_CELLS;
+    const long left = hi - q.c0;
+    q.nv = (wg < cs.g_end[2] && left > 0) ? (int)(left < QS_WG_CELLS ? left : QS_WG_CELLS) : 0;
+    const long cw = q.c0 + (long)wave * QS_CELLS;          // first cell of this wave
+    q.active = q.nv > 0 && cw < hi;
+    q.ci = cw + lane;
+    q.cell_lane = q.active && lane < QS_CELLS && q.ci < hi;
+    q.closing = q.active && lane <= QS_CELLS && q.ci == hi;
+    q.img_cell = cs.sym && q.run == 0 && q.cell_lane && q.ci >= cs.z;
+    q.img_col = cs.sym && q.run == 0 && (q.cell_lane || q.closing) && q.ci > cs.z;
     return q;
+}
+
+// The runs of one row a workgroup writes (element offsets within a row of dxq / daq, of dyq): its own nv cells from c0, and -- mirrored --
+// the three images of its cells [zc, c0 + nv) and of its node columns [zp, c0 + nv).  Shared by the kernel and ogg_symmetry_coverage.
+struct QuadStores {
+    int n_ic, n_ip;         // cells / node columns with images
+    int k0, k1;             // their first entry in the workgroup's row (cell zc - c0, column zp - c0)
+    long cell_up, cell_dn2, cell_dn4;   // images of the cells: ascending from nx/2 + zc; from nx/2 - (c0+nv) and nx - (c0+nv), LAST cell first
+    long col_up, col_dn2, col_dn4;      // of the node columns: from nx/2 + zp; from nx/2 - (c0+nv-1) and nx - (c0+nv-1), last column first
+};
+
+OGG_HD QuadStores quad_stores(const QuadCols& cs, const QuadLane& q, long nx, bool mirrored) {
+    QuadStores s{};
+    const bool sym = mirrored && cs.sym && q.run == 0;
+    const long end = q.c0 + q.nv, h2 = nx / 2;
+    const long zc = sym ? (cs.z > q.c0 ? cs.z : q.c0) : end;
+    const long zp = sym ? (cs.z + 1 > q.c0 ? cs.z + 1 : q.c0) : end;
+    s.n_ic = end > zc ? (int)(end - zc) : 0, s.n_ip = end > zp ? (int)(end - zp) : 0;
+    s.k0 = (int)(zc - q.c0), s.k1 = (int)(zp - q.c0);
+    s.cell_up = h2 + zc, s.cell_dn2 = h2 - end, s.cell_dn4 = nx - end;
+    s.col_up = h2 + zp, s.col_dn2 = h2 - (end - 1), s.col_dn4 = nx - (end - 1);
+    return s;
 }
 
 struct QuadRange {     // the part of the band one grid of strip workgroups evaluates
@@ -641,15 +674,35 @@ inline unsigned tables_blocks(const QuadParams& p) {   // table workgroups + the
     return tables_only_blocks<N>(p) + top_row_blocks<N>(p);
 }
 
-// A wave owns a vertical strip of 63 cells (lane 63 is a halo lane: the first cell of the next strip) and walks up the
+// A wave owns a vertical strip of QS_CELLS = 63 cells (lane 63 is a halo lane: the first cell of the next strip) and walks up the
 // cell rows of its chunk.  Each lane evaluates the (N-1) x (N-1) lattice points of its cell that are not on the cell's
 // right or top edge; the right-edge values are the left-edge values of lane+1 (one wave shuffle), the top-edge row is the
 // bottom row of the next cell row and is evaluated once and reused.  So every unique lattice point of the strip is
 // evaluated exactly once -- (N-1)^2 instead of N^2 evaluations per cell -- with no LDS and no barrier; the row-only
 // factors are wave-uniform (scalar loads), the column-only factors stay in registers for the whole walk.  Sums are taken
 // in the reference's order (OGG:216-221, 244-253).
-constexpr int QS_CELLS = 63;   // cells per wave strip
-constexpr int QS_WAVES = 4;    // strips per workgroup
+//
+// The STORES go through LDS (round 5): what a wave holds is a 504-byte piece of a row that starts anywhere, and a store whose ends split
+// 128-byte lines with the neighbouring waves writes at 5.3 TB/s where whole aligned lines reach 6.6 (scripts/microbench/mirror_writes.hip;
+// with mirrored columns launch B is bound by its writes).  The four strips of a workgroup are 252 consecutive cells: every wave puts its
+// row values into LDS and the workgroup writes the row -- and its three mirror images -- as 128-byte-aligned runs, wave w the elements
+// [64 w, 64 w + 64) counted from the line boundary at or before the run (wg_store_aligned): two split lines per workgroup, row and field
+// instead of eight.
+
+// dst[j] = buf[j0 + sgn j], j = 0 .. n-1 (n <= QS_WG_CELLS), by the four waves of a workgroup: wave w takes the elements of the w-th
+// 512 bytes counted from the 128-byte boundary at or before dst, so that every line inside the run is written whole by one wave (the
+// up to 11 elements past the fourth 512 bytes -- 252 + 15 > 256 -- go with wave 0)
+OGG_DEV void wg_store_aligned(double* __restrict__ dst, int n, const double* buf, int j0, int sgn, int wave, int lane) {
+    const int mis = (int)((reinterpret_cast<unsigned long>(dst) >> 3) & 15ul);   // elements of dst[0] past the line boundary
+    const int j = 64 * wave + lane - mis;
+    if (j >= 0 && j < n) dst[j] = buf[j0 + sgn * j];
+    const int j2 = 64 * QS_WAVES + lane - mis;
+    if (wave == 0 && j2 < n) dst[j2] = buf[j0 + sgn * j2];
+}
+
+struct QuadOutLds {
+    double v[2][3][QS_WG_CELLS];   // [buffer][dxq, dyq, daq][cell of the workgroup]: double-buffered, one barrier per cell row
+};
 
 template <int N, int MODE>
 struct RowEval {
@@ -726,13 +779,16 @@ OGG_DEV void eval_lattice_row(const QuadParams& p, const BpRow& r, const BpCol* 
 }
 
 template <int N, int MODE>
-OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long strip, long by) {  // strip: per wave
+OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, QuadOutLds& out, long wgx, long by) {  // wgx: workgroup along the columns
     constexpr int M = N - 1;
     constexpr bool FAITHFUL = (MODE == QM_LITERAL);
-    const int lane = threadIdx.x & 63;
-    const QuadLane ql = quad_lane(rg.cols, strip, lane, QS_CELLS);
-    if (!ql.active) return;  // wave-uniform
-    const long ci = ql.ci;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const QuadLane ql = quad_lane(rg.cols, wgx, wave, lane);
+    if (ql.nv == 0) return;  // workgroup-uniform: nothing of this workgroup lies inside a run
+    // (a wave without cells -- the last workgroup of a run may be partly filled -- evaluates nothing but stays for the barriers and the stores)
+    const bool active = ql.active;
+    const long ci = ql.ci, c0 = ql.c0;
+    const int nv = ql.nv;
     const long n_cols_tab = M * p.nx + 1;
     BpCol col[M];
 #pragma unroll
@@ -741,60 +797,57 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
         if (u > n_cols_tab - 1) u = n_cols_tab - 1;
         col[ii] = p.col_tab[u];
     }
-    const bool col_lane = ql.col_lane, cell_lane = ql.cell_lane;
-    const bool img_cell = (MODE == QM_FAST) && ql.img_cell, img_col = (MODE == QM_FAST) && ql.img_col;
+    const bool cell_lane = ql.cell_lane, closing = ql.closing;
+    const bool img_col = (MODE == QM_FAST) && ql.img_col;
     const long h2 = p.nx / 2;
+    const QuadStores qs = quad_stores(rg.cols, ql, p.nx, MODE == QM_FAST);   // the cells / node columns of this workgroup that have images
     double rp2p = p.rp2p;
     asm volatile("" : "+v"(rp2p));   // held in a vector register for the whole walk (else re-copied from its scalar register per point)
     RowEval<N, MODE> cur;
     const long r0 = rg.row_begin + by * rg.rows_per_chunk;
     const long r1 = (r0 + rg.rows_per_chunk < rg.row_end) ? r0 + rg.rows_per_chunk : rg.row_end;
-    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, rp2p, true, cur);
+    if (active) eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * r0], col, rp2p, true, cur);
+    const int slot = wave * QS_CELLS + lane;   // this lane's entry of the workgroup's row in LDS
     for (long c = r0; c < r1; ++c) {
-        const double dxq = quad_average_1d<N>(cur.dx) * p.Re;               // OGG:183,186: bottom-edge row
-        int guarded = cur.guarded;                                          // bottom-edge row (carried)
-        double dyc[N];                                                      // dy down this lane's left edge
-        double y2[(N <= 3) ? N * N : 1];
-        double ysum = 0.0;
+        double dxq = 0.0, dyq = 0.0, da = 0.0;
+        int guarded = 0;
+        if (active) {
+            dxq = quad_average_1d<N>(cur.dx) * p.Re;                        // OGG:183,186: bottom-edge row
+            guarded = cur.guarded;                                          // bottom-edge row (carried)
+            double dyc[N];                                                  // dy down this lane's left edge
+            double y2[(N <= 3) ? N * N : 1];
+            double ysum = 0.0;
 #pragma unroll
-        for (int k = 0; k < N; ++k) dyc[k] = 0.0;
+            for (int k = 0; k < N; ++k) dyc[k] = 0.0;
 #pragma unroll((N <= 3 || MODE != QM_LITERAL) ? N : 1)
-        for (int jj = 0; jj < N; ++jj) {
-            if (jj > 0) {
-                // the top row of this cell row is the bottom row of the next one.  Every cell-edge lattice row is evaluated in the
-                // edge form (dx and dy separately), also the last one of a chunk, whose dx nobody reads: the area of a cell must not
-                // depend on where the chunks -- hence the bands of a sharded run -- end
-                eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, rp2p, jj == M, cur);
-                guarded |= cur.guarded;
-            }
-            const double wj = quad_weight_1d<N>(jj);
-#pragma unroll
-            for (int ii = 0; ii < N; ++ii) {
-                const double pr = cur.pr[ii];
-                if (N <= 3) {
-#pragma unroll
-                    for (int k = 0; k < N * N; ++k)
-                        if (N <= 3 && k == jj * N + ii) y2[(N <= 3) ? k : 0] = pr;
-                } else {
-                    if (FAITHFUL)
-                        ysum = ysum + (quad_weight_1d<N>(ii) * wj) * pr;    // OGG:244 / 252
-                    else
-                        ysum = fma(quad_weight_1d<N>(ii) * wj, pr, ysum);
+            for (int jj = 0; jj < N; ++jj) {
+                if (jj > 0) {
+                    // the top row of this cell row is the bottom row of the next one.  Every cell-edge lattice row is evaluated in the
+                    // edge form (dx and dy separately), also the last one of a chunk, whose dx nobody reads: the area of a cell must not
+                    // depend on where the chunks -- hence the bands of a sharded run -- end
+                    eval_lattice_row<N, MODE>(p, p.row_tab[(long)M * c + jj], col, rp2p, jj == M, cur);
+                    guarded |= cur.guarded;
                 }
-            }
+                const double wj = quad_weight_1d<N>(jj);
 #pragma unroll
-            for (int k = 0; k < N; ++k) dyc[k] = (jj == k) ? cur.dy0 : dyc[k];
-        }
-        // cur now holds lattice row (c, N-1) == (c+1, 0): the bottom row of the next cell row
-        const long out_r = c - p.j0;
-        if (col_lane) {
-            const double dyq = quad_average_1d<N>(dyc) * p.Re;                                // OGG:184,187
-            double* __restrict__ row = p.dyq + out_r * (p.nx + 1);
-            row[ci] = dyq;
-            if (img_col) row[h2 - ci] = dyq, row[h2 + ci] = dyq, row[p.nx - ci] = dyq;
-        }
-        if (cell_lane) {
-            double da;
+                for (int ii = 0; ii < N; ++ii) {
+                    const double pr = cur.pr[ii];
+                    if (N <= 3) {
+#pragma unroll
+                        for (int k = 0; k < N * N; ++k)
+                            if (N <= 3 && k == jj * N + ii) y2[(N <= 3) ? k : 0] = pr;
+                    } else {
+                        if (FAITHFUL)
+                            ysum = ysum + (quad_weight_1d<N>(ii) * wj) * pr;    // OGG:244 / 252
+                        else
+                            ysum = fma(quad_weight_1d<N>(ii) * wj, pr, ysum);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < N; ++k) dyc[k] = (jj == k) ? cur.dy0 : dyc[k];
+            }
+            // cur now holds lattice row (c, N-1) == (c+1, 0): the bottom row of the next cell row
+            dyq = quad_average_1d<N>(dyc) * p.Re;                               // OGG:184,187
             if (N == 2) {
                 const double d = 1.0 / 2.0;
                 da = d * d * (y2[0] + y2[1] + y2[(N <= 3) ? N : 0] + y2[(N <= 3) ? N + 1 : 0]);
@@ -806,23 +859,46 @@ OGG_DEV void bipolar_quad_body(const QuadParams& p, const QuadRange& rg, long st
                 const double d = (N == 4) ? (1.0 / 12.0) : (1.0 / 180.0);
                 da = d * d * ysum;
             }
-            da = da * p.Re * p.Re;                                                            // OGG:185
-            double* __restrict__ rdx = p.dxq + out_r * p.nx;
-            double* __restrict__ rda = p.daq + out_r * p.nx;
-            rdx[ci] = dxq;
-            rda[ci] = da;
-            if (img_cell) {
-                rdx[h2 - 1 - ci] = dxq, rdx[h2 + ci] = dxq, rdx[p.nx - 1 - ci] = dxq;
-                rda[h2 - 1 - ci] = da, rda[h2 + ci] = da, rda[p.nx - 1 - ci] = da;
-            }
-            if (MODE == QM_GUARD && guarded) p.fix_list[atomicAdd(p.fix_count, 1u)] = (unsigned)(out_r * p.nx + ci);
+            da = da * p.Re * p.Re;                                              // OGG:185
+        }
+        const long out_r = c - p.j0;
+        double* __restrict__ rdx = p.dxq + out_r * p.nx;
+        double* __restrict__ rdy = p.dyq + out_r * (p.nx + 1);
+        double* __restrict__ rda = p.daq + out_r * p.nx;
+        // the node column behind the run's last cell (the halo lane of the run's last strip): dyq only, stored directly
+        if (closing) {
+            rdy[ci] = dyq;
+            if (img_col) rdy[h2 - ci] = dyq, rdy[h2 + ci] = dyq, rdy[p.nx - ci] = dyq;
+        }
+        if (cell_lane && MODE == QM_GUARD && guarded) p.fix_list[atomicAdd(p.fix_count, 1u)] = (unsigned)(out_r * p.nx + ci);
+        // the row of the workgroup through LDS, then whole 128-byte lines to the arrays
+        double(*buf)[QS_WG_CELLS] = out.v[(c - r0) & 1];
+        if (lane < QS_CELLS) buf[0][slot] = dxq, buf[1][slot] = dyq, buf[2][slot] = da;
+        __syncthreads();   // (one barrier per cell row: the other buffer was read a whole cell row of arithmetic ago)
+        wg_store_aligned(rdx + c0, nv, buf[0], 0, 1, wave, lane);
+        wg_store_aligned(rdy + c0, nv, buf[1], 0, 1, wave, lane);
+        wg_store_aligned(rda + c0, nv, buf[2], 0, 1, wave, lane);
+        const int last = nv - 1;
+        if (qs.n_ic > 0) {   // nx/2 + i ascending; nx/2 - 1 - i and nx - 1 - i descend in i, i.e. ascend from the workgroup's last cell
+            wg_store_aligned(rdx + qs.cell_up, qs.n_ic, buf[0], qs.k0, 1, wave, lane);
+            wg_store_aligned(rda + qs.cell_up, qs.n_ic, buf[2], qs.k0, 1, wave, lane);
+            wg_store_aligned(rdx + qs.cell_dn2, qs.n_ic, buf[0], last, -1, wave, lane);
+            wg_store_aligned(rda + qs.cell_dn2, qs.n_ic, buf[2], last, -1, wave, lane);
+            wg_store_aligned(rdx + qs.cell_dn4, qs.n_ic, buf[0], last, -1, wave, lane);
+            wg_store_aligned(rda + qs.cell_dn4, qs.n_ic, buf[2], last, -1, wave, lane);
+        }
+        if (qs.n_ip > 0) {   // node columns: nx/2 + i; nx/2 - i and nx - i from the last column
+            wg_store_aligned(rdy + qs.col_up, qs.n_ip, buf[1], qs.k1, 1, wave, lane);
+            wg_store_aligned(rdy + qs.col_dn2, qs.n_ip, buf[1], last, -1, wave, lane);
+            wg_store_aligned(rdy + qs.col_dn4, qs.n_ip, buf[1], last, -1, wave, lane);
         }
     }
 }
 
 template <int N, int MODE>
 __global__ __launch_bounds__(64 * QS_WAVES) void bipolar_quad_kernel(QuadParams p, QuadRange rg) {
-    bipolar_quad_body<N, MODE>(p, rg, (long)blockIdx.x * QS_WAVES + (threadIdx.x >> 6), blockIdx.y);
+    __shared__ QuadOutLds out;
+    bipolar_quad_body<N, MODE>(p, rg, out, blockIdx.x, blockIdx.y);
 }
 
 // Literal re-evaluation (bp_point, OGG:41-95 operation for operation) of the cells the guard handed over: half a wave per
@@ -958,8 +1034,11 @@ constexpr double BP_SYM_FOLD_DEG = 6.0;   // QuadCols: degrees of longitude next
 // 4 (the pole meridians are node columns) and the literal zones leave something to mirror
 inline QuadCols quad_cols(long nx, int symmetry) {
     QuadCols c{};
-    c.r1 = c.r2 = c.total = nx + 1;
-    c.lo1 = c.lo2 = 0, c.z = nx, c.sym = 0;
+    auto wgs = [](long lo, long hi) { return (hi - lo + QS_WG_CELLS - 1) / QS_WG_CELLS; };
+    for (int r = 0; r < 3; ++r) c.lo[r] = c.hi[r] = 0;
+    c.lo[0] = 0, c.hi[0] = nx;
+    c.g_end[0] = c.g_end[1] = c.g_end[2] = wgs(0, nx);
+    c.z = nx, c.sym = 0;
     if (!symmetry || nx % 4 != 0) return c;
     double deg = BP_SYM_FOLD_DEG;
     if (const char* e = getenv("OGG_BP_SYM_FOLD_DEG")) deg = atof(e);
@@ -968,9 +1047,11 @@ inline QuadCols quad_cols(long nx, int symmetry) {
     if (z < 1) z = 1;
     if (2 * z > q) return c;
     c.sym = 1, c.z = z;
-    c.r1 = q + 1;                  // cells [0, q) + column q
-    c.lo1 = 2 * q - z, c.r2 = c.r1 + 2 * z + 1;   // cells [nx/2 - z, nx/2 + z) + column nx/2 + z
-    c.lo2 = nx - z, c.total = c.r2 + z + 1;       // cells [nx - z, nx) + column nx
+    c.lo[0] = 0, c.hi[0] = q;                    // cells [0, q), closed by column q
+    c.lo[1] = 2 * q - z, c.hi[1] = 2 * q + z;    // cells [nx/2 - z, nx/2 + z), closed by column nx/2 + z
+    c.lo[2] = nx - z, c.hi[2] = nx;              // cells [nx - z, nx), closed by column nx
+    long g = 0;
+    for (int r = 0; r < 3; ++r) g += wgs(c.lo[r], c.hi[r]), c.g_end[r] = g;
     return c;
 }
 
@@ -1013,8 +1094,9 @@ int plan_quad(QuadParams p, long n_dx_rows, long n_cell_rows, double guard_k, in
         r.row_begin = b;
         r.row_end = e;
         r.cols = quad_cols(p.nx, sym);
-        const long n_strips = (r.cols.total + QS_CELLS - 1) / QS_CELLS;
-        r.gx = (unsigned)((n_strips + QS_WAVES - 1) / QS_WAVES);
+        r.gx = (unsigned)r.cols.g_end[2];
+        long n_strips = 0;   // strips that hold cells
+        for (int k = 0; k < 3; ++k) n_strips += (r.cols.hi[k] - r.cols.lo[k] + QS_CELLS - 1) / QS_CELLS;
         // enough waves to fill 1024 SIMDs (x 3 wave slots) more than once, without recomputing more than 1-2 % of the lattice rows (8192: +1.5 %)
         long target = 4096;
         if (const char* ev = getenv("OGG_QUAD_TARGET_WAVES")) target = atol(ev) > 0 ? atol(ev) : target;

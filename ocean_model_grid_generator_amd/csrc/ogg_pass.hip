@@ -59,6 +59,7 @@ union PassLds {
     RowScalars ll[LF_ROWS + 1];
     BpRow mesh[MESH_ROWS_MAX];
     DpMeshLds dmesh;
+    QuadOutLds quad;
 };
 
 struct PassAParams {
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
         dpole_mesh_body(a.dm, lds.dmesh, t % a.dm.gx, t / a.dm.gx);
     } else if (role == ROLE_BP_GUARD) {
         asm volatile("; role: guarded quadrature strips" ::: "memory");
-        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, (b % a.guard.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.guard.gx);
+        bipolar_quad_body<N, QM_GUARD>(a.q, a.guard, lds.quad, b % a.guard.gx, b / a.guard.gx);
     } else if (role == ROLE_BP_FAST) {
         asm volatile("; role: quadrature strips" ::: "memory");
-        bipolar_quad_body<N, QM_FAST>(a.q, a.fast, (b % a.fast.gx) * QS_WAVES + (threadIdx.x >> 6), b / a.fast.gx);
+        bipolar_quad_body<N, QM_FAST>(a.q, a.fast, lds.quad, b % a.fast.gx, b / a.fast.gx);
     } else if (role == ROLE_DP_QUAD) {
         const long strip = (b % a.dq.gx) * DQ_WAVES + (threadIdx.x >> 6), chunk = b / a.dq.gx;
         if (a.dq_order == 2)
@@ -234,12 +235,14 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     s.points = points;
     // measured optima (1/8 degree, shares 1, 1/2, 1/4, 1/8 = 19.8, 9.9, 5, 2.5 M points): 60, 90, 90-120, 120 -- the smaller the share,
     // the shorter the VALU work the strips can hide behind, so they need more of the write bandwidth
-    // `light`: the caps' columns are mirrored (OGG_SYM_MIRROR: a third of the cap arithmetic): a launch that no longer fills the chip
-    // with VALU work for as long wants more of it writing -- half and quarter of the 1/8 degree grid 180 (measured: 0.1229 -> 0.1133 ms,
-    // 0.0583 -> 0.0566 ms), the whole grid and an eighth as before
+    // `light`: the caps' columns are mirrored (OGG_SYM_MIRROR: a third of the cap arithmetic).  The launch is then bound by its WRITES at
+    // every size (VALU busy 28 %, no power limit: profiles/r05_*), the cap workgroups drain early, and the strips want more of the chip
+    // for the whole launch instead of helpers at its end: round-robin sweeps on three boxes (scripts/config_sweep.py; helpers off) --
+    // whole 1/8 degree grid 144-192 resident workgroups within 1 % of each other and 4-10 % faster than 90 + helpers, 1/16 degree 161
+    // (184: +1.5 %, 138: +1 %), half / quarter of the 1/8 degree grid 150-180, an eighth 120 as before
     long max_wg = alone ? 2048
-                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", 90)
-                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", light ? 180 : 90)
+                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", light ? 156 : 90)
+                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", light ? 150 : 90)
                                                                    : env_long("OGG_PASS_LL_WG_SMALL", (light && points >= 4000000) ? 180 : 120)));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
@@ -377,12 +380,17 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         const char* ord = getenv("OGG_PASS_ORDER");
         for (int k = 0; k < N_ROLES; ++k)
             B.order[k] = (ord && strlen(ord) == N_ROLES && ord[k] >= '0' && ord[k] < '0' + N_ROLES) ? ord[k] - '0' : dflt[k];
-        B.share = make_share(ll, s1, n_strips_ll, ni1, false, have_cap && ogg::cap_symmetry(cap->symmetry));
+        // `light`: mirrored caps and no displaced-pole quadrature in this launch (with one, the launch still carries enough arithmetic for
+        // the strips to hide behind: 1/8 degree with the displaced pole 0.257 ms at 90 resident workgroups, 0.269 at 120, 0.285 at 150)
+        const bool light = have_cap && ogg::cap_symmetry(cap->symmetry) && B.n_dquad == 0;
+        B.share = make_share(ll, s1, n_strips_ll, ni1, false, light);
         // helper workgroups for the lat-lon strips at the end of the launch (ogg_latlon_fused_dev.h): the claim counters live in the
         // bipolar cap's workspace and are zeroed by launch A with its tables
         // (measured: 1/8 degree whole grid 0.246 -> 0.237 ms, 1/16 degree 1.23 -> 1.19; half, a quarter, an eighth of the 1/8 degree grid
         // +1 %, +1 %, +4 %: the claims cost more than a tail that short gives back -- whole-grid launches only)
-        const long helpers = env_long("OGG_PASS_LL_HELPERS", B.share.points >= 16000000 ? 2 : 0);
+        // (mirrored caps: the compute roles drain early, helpers would join almost at once and only add writers -- measured 2-5 % slower
+        // than none on three boxes: off)
+        const long helpers = env_long("OGG_PASS_LL_HELPERS", (B.share.points >= 16000000 && !light) ? 2 : 0);
         if (have_quad && helpers > 0 && B.share.n_wg > 0 && 2 * B.share.n_wg <= QUAD_LL_CLAIM_WORDS) {
             B.share.claims = qp.p.ll_claims;
             B.share.n_help = B.share.n_wg * helpers;
@@ -621,23 +629,33 @@ extern "C" int ogg_symmetry_coverage(int which, int order, long n, double lon0, 
         if (c != a && c != b) w[c] += 1;
         if (d != a && d != b && d != c) w[d] += 1;
     };
-    if (which == 0) {
+    if (which == 0) {   // the runs the workgroups store (quad_stores: the same offsets the kernel uses) + the closing columns, stored by their lanes
         const QuadCols cs = quad_cols(n, sym);
-        const long h2 = n / 2, n_strips = (cs.total + QS_CELLS - 1) / QS_CELLS;
-        for (long strip = 0; strip < n_strips; ++strip)
-            for (int lane = 0; lane < 64; ++lane) {
-                const QuadLane q = quad_lane(cs, strip, lane, QS_CELLS);
-                if (!q.active) continue;
-                if (q.col_lane) {
-                    *evaluated += 1;
-                    if (q.img_col) bump(col_writes, q.ci, h2 - q.ci, h2 + q.ci, n - q.ci);
-                    else col_writes[q.ci] += 1;
+        const long h2 = n / 2;
+        for (long wg = 0; wg < cs.g_end[2]; ++wg) {
+            const QuadLane q0 = quad_lane(cs, wg, 0, 0);
+            if (q0.nv == 0) continue;
+            const QuadStores st = quad_stores(cs, q0, n, true);
+            *evaluated += q0.nv;
+            for (long k = 0; k < q0.nv; ++k) cell_writes[q0.c0 + k] += 1, col_writes[q0.c0 + k] += 1;
+            for (long k = 0; k < st.n_ic; ++k) cell_writes[st.cell_up + k] += 1, cell_writes[st.cell_dn2 + k] += 1, cell_writes[st.cell_dn4 + k] += 1;
+            for (long k = 0; k < st.n_ip; ++k) col_writes[st.col_up + k] += 1, col_writes[st.col_dn2 + k] += 1, col_writes[st.col_dn4 + k] += 1;
+            for (int wave = 0; wave < QS_WAVES; ++wave)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const QuadLane q = quad_lane(cs, wg, wave, lane);
+                    OGG_REQUIRE(q.nv == q0.nv && q.c0 == q0.c0, OGG_EARG, "ogg_symmetry_coverage: workgroup-uniform values differ");
+                    OGG_REQUIRE(!q.cell_lane || (q.ci >= q.c0 && q.ci < q.c0 + q.nv && q.ci - q.c0 == wave * QS_CELLS + lane), OGG_EARG,
+                                "ogg_symmetry_coverage: a cell lane outside its workgroup's row");
+                    OGG_REQUIRE(q.img_cell == (q.cell_lane && st.n_ic > 0 && q.ci - q.c0 >= st.k0) &&
+                                    (q.closing || q.img_col == (q.cell_lane && st.n_ip > 0 && q.ci - q.c0 >= st.k1)), OGG_EARG,
+                                "ogg_symmetry_coverage: image flags of a lane and image runs of its workgroup disagree");
+                    if (q.closing) {
+                        *evaluated += 1;
+                        if (q.img_col) bump(col_writes, q.ci, h2 - q.ci, h2 + q.ci, n - q.ci);
+                        else col_writes[q.ci] += 1;
+                    }
                 }
-                if (q.cell_lane) {
-                    if (q.img_cell) bump(cell_writes, q.ci, h2 - 1 - q.ci, h2 + q.ci, n - 1 - q.ci);
-                    else cell_writes[q.ci] += 1;
-                }
-            }
+        }
     } else if (which == 1) {
         const MeshCols mc = mesh_cols(n, sym);
         const long h2 = n / 2;

@@ -719,9 +719,13 @@ class Supergrid(object):
                 self._timed("tile_latlon", lambda: L.call("ogg_tile_latlon_dev", rows, ni1, self._p(b["axis"], s.row0 + b["lo"]),
                                                           self.lon1d.data_ptr(), b["x"].data_ptr(), b["y"].data_ptr(), st))
             elif s.kind == "bipolar":
-                self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_sym_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
-                                                           p.cap_symmetry, b["x"].data_ptr(), b["y"].data_ptr(), None, None,
-                                                           b["angle_dx"].data_ptr(), st))
+                if hasattr(L.load(), "ogg_bipolar_cap_mesh_angle_sym_dev"):
+                    self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_sym_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
+                                                               p.cap_symmetry, b["x"].data_ptr(), b["y"].data_ptr(), None, None,
+                                                               b["angle_dx"].data_ptr(), st))
+                else:   # an older build under A/B timing (OGG_LIB_PATH, scripts/ab_time.py): every column
+                    self._timed("bipolar_mesh", lambda: L.call("ogg_bipolar_cap_mesh_angle_dev", p.Ni, s.Nj, s.lat0_bp, s.lon_bp, b["lo"], b["n"],
+                                                               b["x"].data_ptr(), b["y"].data_ptr(), None, None, b["angle_dx"].data_ptr(), st))
             elif s.kind == "dpole":   # mesh, unwrap and angle_dx in one launch (its look-back words: the head of the band's workspace)
                 self._timed("dpole_mesh", lambda: L.call("ogg_displaced_pole_grid_angle_ws_dev", p.Ni, s.Nj, p.lon0, s.lat0, s.lon_dp, s.r_dp,
                                                          s.row0 + b["lo"], b["n"], b["x"].data_ptr(), b["y"].data_ptr(),
@@ -787,13 +791,21 @@ class Supergrid(object):
             else:
                 if not p.skip_metrics:
                     if s.kind == "bipolar":
-                        self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_sym_ws_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
-                                                                   s.rp, p.Re, b["lo"], b["n"], b["n_cell"], p.cap_symmetry, b["dx"].data_ptr(),
-                                                                   b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
-                                                                   b["ws_bytes"], st))
+                        if hasattr(L.load(), "ogg_bipolar_cap_metrics_quad_sym_ws_dev"):
+                            self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_sym_ws_dev", 5, p.Ni, s.Nj, s.lat0_bp,
+                                                                       s.lon_bp, s.rp, p.Re, b["lo"], b["n"], b["n_cell"], p.cap_symmetry,
+                                                                       b["dx"].data_ptr(), b["dy"].data_ptr(), b["area"].data_ptr(),
+                                                                       b["ws"].data_ptr(), b["ws_bytes"], st))
+                        else:   # an older build under A/B timing
+                            self._timed("bipolar_quad", lambda: L.call("ogg_bipolar_cap_metrics_quad_ws_dev", 5, p.Ni, s.Nj, s.lat0_bp, s.lon_bp,
+                                                                       s.rp, p.Re, b["lo"], b["n"], b["n_cell"], b["dx"].data_ptr(),
+                                                                       b["dy"].data_ptr(), b["area"].data_ptr(), b["ws"].data_ptr(),
+                                                                       b["ws_bytes"], st))
                     else:
                         j0 = s.row0 + b["lo"]
-                        self._timed("dpole_quad", lambda: L.call("ogg_displaced_pole_metrics_quad_form_sym_ws_dev", p.dp_arc, p.cap_symmetry, 4, p.Ni, s.Nj, p.lon0,
+                        has_sym = hasattr(L.load(), "ogg_displaced_pole_metrics_quad_form_sym_ws_dev")   # (not in an older build under A/B timing)
+                        self._timed("dpole_quad", lambda: L.call(*(("ogg_displaced_pole_metrics_quad_form_sym_ws_dev", p.dp_arc, p.cap_symmetry) if has_sym
+                                                                   else ("ogg_displaced_pole_metrics_quad_form_ws_dev", p.dp_arc)), 4, p.Ni, s.Nj, p.lon0,
                                                                  s.lat0, s.lon_dp, s.r_dp, p.Re, j0, b["n"], b["n_cell"], b["dx"].data_ptr(),
                                                                  b["dy"].data_ptr() if b["n_cell"] else None,
                                                                  b["area"].data_ptr() if b["n_cell"] else None,

@@ -131,7 +131,7 @@ void check_quad_plan(long nx, long ny, long j0, long n_cell_rows, bool top, int 
     long covered = 0;
     if (q.has_fast) {
         covered += q.fast.row_end - q.fast.row_begin;
-        CHECK(q.fast.gx > 0 && q.fast.gy > 0 && q.fast.cols.total > 0, "empty fast grid");
+        CHECK(q.fast.gx > 0 && q.fast.gy > 0 && q.fast.cols.g_end[2] == q.fast.gx, "empty fast grid");
     }
     if (q.has_guard) {
         covered += q.guard.row_end - q.guard.row_begin;
