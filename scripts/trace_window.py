@@ -36,12 +36,20 @@ def main():
     steps, region = bench["steps"], bench["timed_region_clock_ns"]
     rows = [(clean(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace))]
     dom = bench["roofline"]["kernel"].split("<")[0]
+    if not any(k.startswith(dom) for k, _, _ in rows):
+        # (the stencil pipeline's bench line names its kernels by pipeline stage, not by function: take the kernel with the most time)
+        tot = {}
+        for k, s, e in rows:
+            tot[k.split("<")[0]] = tot.get(k.split("<")[0], 0) + (e - s)
+        dom = max((k for k in tot if not k.startswith(("__amd", "at::"))), key=lambda k: tot[k])
     best = None
     for clock, (a, b) in region.items():
         n = sum(1 for k, s, e in rows if k.startswith(dom) and s >= a and e <= b + 2_000_000)   # the last launch may end after the host's stamp
-        if best is None or abs(n - steps) < abs(best[1] - steps):
-            best = (clock, n, a, b)
-    clock, n_dom, a, b = best
+        # the region holds a multiple of `steps` launches of the dominant kernel on the right clock, none (or all of the trace) on a wrong one
+        score = abs(n - steps * max(1, round(n / steps))) if n else 10 ** 9
+        if best is None or score < best[4] or (score == best[4] and n > best[1]):
+            best = (clock, n, a, b, score)
+    clock, n_dom, a, b, _ = best
     per_all, per_win = {}, {}
     for k, s, e in rows:
         per_all.setdefault(k, []).append(e - s)
