@@ -5,7 +5,6 @@ workgroups), and the fused 1/16 degree pass.  usage: python3 scripts/box_probe.p
 import json
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402

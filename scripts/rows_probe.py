@@ -1,9 +1,8 @@
 """The (field, row)-ordered lat-lon kernel (OGG_LATLON_ROWS=1) against the column-tile kernel, stand-alone, in one process on one box:
 1/8, 1/16 and 1/2 degree."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, "/root/repo")
 import torch
-import numpy as np
 from ocean_model_grid_generator_amd import supergrid as SG
 import bench
 for wl in ("r8", "r16", "r2"):

@@ -13,7 +13,6 @@ import csv
 import glob
 import json
 import os
-import re
 import shutil
 import sys
 
