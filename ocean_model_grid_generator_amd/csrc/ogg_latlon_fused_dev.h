@@ -148,6 +148,25 @@ OGG_DEV void latlon_rows(const FusedParams& p, const ogg_latlon_band& b, const R
     }
 }
 
+// A ticket from a counter in global memory whose answer is not waited for where it is asked.  hipcc's atomicAdd() waits for the returned
+// value on the spot (`s_waitcnt vmcnt(0)`: every store this wave has in flight must land first).  Vector-memory operations of a wave
+// complete in the order they were issued, so once at most LATER of the operations issued after the question are still outstanding the answer
+// is there: ticket_answer<LATER> is safe when the wave has issued at least LATER vector-memory operations since ticket_ask.
+OGG_DEV unsigned ticket_ask(unsigned* counter) {
+    unsigned ret;
+    const unsigned one = 1u;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(counter), "v"(one) : "memory");
+    return ret;
+}
+// The compiler takes the register ticket_ask returns for a value that is already there: nothing but ticket_answer may read it (no
+// initialiser, no loop-carried copy of it -- a copy made before the wait would copy the register's old content).
+template <int LATER>
+OGG_DEV unsigned ticket_answer(unsigned pending) {
+    unsigned out;
+    asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, %1" : "=v"(out) : "v"(pending), "n"(LATER) : "memory");
+    return out;
+}
+
 constexpr int LF_COLS = 2 * LF_TX;  // columns per workgroup: every thread owns two adjacent columns
 inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
 
@@ -166,7 +185,7 @@ inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
 // workgroups running) the whole chip finishes them; if not, they find nothing to claim and leave.  s_claim: one LDS word.
 template <bool NT>
 OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi,
-                               unsigned* claims = nullptr, bool helper = false, int* s_claim = nullptr) {
+                               unsigned* claims = nullptr, bool helper = false, int* s_claim = nullptr, bool pool = false) {
     const long v = xcd_contiguous(b, gx * gy);   // virtual index: the workgroups of XCD x are consecutive
     const long bx = v % gx, by = v / gx;
     const int tid = threadIdx.x;
@@ -178,10 +197,29 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
     // VALU-bound workgroups can share the CUs; each workgroup walks its block of row strips.
     const long per = (strip_hi - strip_lo + gy - 1) / gy;
     const long s_first = strip_lo + by * per, s_last = (s_first + per < strip_hi) ? s_first + per : strip_hi;
-    unsigned* cnt = claims ? claims + 2 * (by * gx + bx) : nullptr;
+    // `pool`: the strips of a column tile are handed out from ONE counter per tile, in row order, to whichever of the tile's workgroups
+    // asks next.  The eight XCDs do not write at the same rate -- XCD 2k + 1 gets 40 % of what the pair (2k, 2k + 1) sustains while both
+    // are writing (scripts/microbench/xcd_write.hip) -- and with equal shares the launch waits for the slow half of the chip.
+    unsigned* cnt = claims ? (pool ? claims + bx : claims + 2 * (by * gx + bx)) : nullptr;
+    const unsigned n_pool = (unsigned)(strip_hi - strip_lo);
+    if (pool) {
+        if (tid == 0) {
+            const unsigned t = atomicAdd(cnt, 1u);
+            *s_claim = t < n_pool ? (int)t : -1;
+        }
+        __syncthreads();
+    }
     long walked = 0;   // strips this workgroup has taken (wave-uniform)
     for (long strip = s_first;; ++strip) {
-        if (cnt) {
+        unsigned asked;   // (thread 0, pool) the ticket for the NEXT strip, asked for while this one is written
+        if (pool) {
+            const int pick = *s_claim;   // written before the barrier that ended the previous strip
+            if (pick < 0) break;
+            strip = strip_lo + pick;
+            // the next ticket is asked for BEFORE this strip's stores are issued: its answer travels ahead of them, and nobody waits for it
+            // until they are all on their way
+            if (tid == 0) asked = ticket_ask(cnt);
+        } else if (cnt) {
             if (tid == 0) {
                 const unsigned n = (unsigned)(s_last > s_first ? s_last - s_first : 0);
                 int pick = -1;
@@ -228,6 +266,11 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
             latlon_rows<true, NT>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
         else if (i0 < ni1)  // the last column (ni1 odd) or the last pair (no dx / area in its second column)
             latlon_rows<false, NT>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
+        if (pool && tid == 0) {
+            // this wave has issued at least three stores per row since it asked (x, y, angle_dx of its first column)
+            const unsigned t = nrows >= 6 ? ticket_answer<16>(asked) : ticket_answer<0>(asked);
+            *s_claim = t < n_pool ? (int)t : -1;
+        }
         __syncthreads();  // the row table is rewritten by the next strip
     }
 }

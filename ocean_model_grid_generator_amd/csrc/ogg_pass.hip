@@ -52,6 +52,7 @@ struct LatlonShare {
     int nt;         // non-temporal stores (ogg_latlon_fused_dev.h, store2): when the strips share the launch with cap workgroups
     unsigned* claims;   // claim counters of the strips (2 per resident workgroup; zeroed by launch A), or NULL: every workgroup its block
     long n_help;        // helper workgroups at the END of the launch (claims != NULL): n_wg * OGG_PASS_LL_HELPERS
+    int pool;           // claims != NULL: one counter per column tile, every strip of the tile handed out from it (no helpers)
     long points;        // lat-lon points of the strips (host side: size class of the launch)
 };
 
@@ -150,14 +151,59 @@ struct PassBParams {
 enum { ROLE_BP_MESH = 0, ROLE_DP_MESH, ROLE_BP_GUARD, ROLE_BP_FAST, ROLE_DP_QUAD, N_ROLES };
 
 
+#ifdef OGG_TIMELINE
+// experiment builds only (scripts/ab_build.sh WORK tl -DOGG_TIMELINE=1; scripts/pass_timeline.py): when do the workgroups of each role of
+// launch B start and end?  Slot r: 0 resident strips, 1 helpers, 2 + ROLE_*, 7 the next pass's tables.  100 MHz constant clock.
+__device__ unsigned long long g_tl_first[8], g_tl_last_start[8], g_tl_end[8], g_tl_sum_end[8], g_tl_n[8];
+__device__ unsigned long long g_tl_strip_end[512];   // end of every resident strip workgroup, by workgroup index
+struct Timeline {
+    unsigned long long t0;
+    __device__ Timeline() : t0(wall_clock64()) {}
+    __device__ void done(int r) const {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t1 = wall_clock64();
+            atomicMin(&g_tl_first[r], t0), atomicMax(&g_tl_last_start[r], t0), atomicMax(&g_tl_end[r], t1);
+            atomicAdd(&g_tl_sum_end[r], t1), atomicAdd(&g_tl_n[r], 1ull);
+            if (r == 0 && blockIdx.x < 512) g_tl_strip_end[blockIdx.x] = t1;
+        }
+    }
+};
+extern "C" int ogg_timeline(unsigned long long* out40, int reset) {
+    unsigned long long h[40];
+    const void* sym[5] = {g_tl_first, g_tl_last_start, g_tl_end, g_tl_sum_end, g_tl_n};
+    for (int k = 0; k < 5; ++k)
+        if (hipMemcpyFromSymbol(h + 8 * k, sym[k], 64) != hipSuccess) return 1;
+    if (out40) memcpy(out40, h, sizeof h);
+    if (reset) {
+        unsigned long long z[8] = {}, big[8];
+        for (int k = 0; k < 8; ++k) big[k] = ~0ull;
+        if (hipMemcpyToSymbol(g_tl_first, big, 64) != hipSuccess) return 1;
+        for (int k = 1; k < 5; ++k)
+            if (hipMemcpyToSymbol(sym[k], z, 64) != hipSuccess) return 1;
+    }
+    return 0;
+}
+extern "C" int ogg_timeline_strips(unsigned long long* out512) {
+    return hipMemcpyFromSymbol(out512, g_tl_strip_end, sizeof g_tl_strip_end) == hipSuccess ? 0 : 1;
+}
+#define OGG_TL_DONE(r) tl.done(r)
+#else
+#define OGG_TL_DONE(r)
+#endif
+
 template <int N>
 __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
     __shared__ PassLds lds;
     __shared__ unsigned s_slot;
     __shared__ int s_claim;
+#ifdef OGG_TIMELINE
+    const Timeline tl;
+#endif
     long b = blockIdx.x;
     if (b >= (long)gridDim.x - a.n_next) {   // (n_next = 0: never)
         pass_table_roles<N>(*a.next, b - ((long)gridDim.x - a.n_next));
+        OGG_TL_DONE(7);
         return;
     }
     const long first_help = (long)gridDim.x - a.n_next - a.share.n_help;
@@ -170,9 +216,10 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
             b = r % n;
         }
         if (a.share.nt)
-            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim);
+            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim, a.share.pool != 0);
         else
-            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim);
+            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim, a.share.pool != 0);
+        OGG_TL_DONE(helper ? 1 : 0);
         return;
     }
     b -= a.share.n_wg;
@@ -206,6 +253,7 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
         else
             dpole_quad_body<4, DP_ARC_CHORD>(a.dq, strip, chunk);
     }
+    OGG_TL_DONE(2 + role);
 }
 
 // launch D: the displaced-pole quadrature in the reference's literal arithmetic (256 VGPRs, 70 KB of LDS: its own launch)
@@ -223,7 +271,9 @@ long env_long(const char* name, long dflt) {
     return e ? atol(e) : dflt;
 }
 
-LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone, bool light = false) {
+// pool: 0 = every resident workgroup its own block of strips, 1 = the strips of a column tile are handed out from one counter
+// (ogg_latlon_fused_dev.h), -1 = the default: pooled when the launch is `light` or carries >= 16 M lat-lon points (OGG_PASS_LL_POOL overrides)
+LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone, bool light = false, int pool = 0) {
     LatlonShare s{};
     s.gx = latlon_gx(ni1);
     s.strip_lo = lo, s.strip_hi = hi;
@@ -240,10 +290,19 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // for the whole launch instead of helpers at its end: round-robin sweeps on three boxes (scripts/config_sweep.py; helpers off) --
     // whole 1/8 degree grid 144-192 resident workgroups within 1 % of each other and 4-10 % faster than 90 + helpers, 1/16 degree 161
     // (184: +1.5 %, 138: +1 %), half / quarter of the 1/8 degree grid 150-180, an eighth 120 as before
+    // pooled strips (round 5, after the mirrored caps): every XCD takes what it can write, the strips end together, and FEWER resident
+    // workgroups are best -- the cap workgroups get the wave slots, the strips still end with them: 1/8 degree 84-96 (0.2171 -> 0.2005 ms
+    // on a fast box, 0.2397 -> 0.2158 on a slow one; 156: 0.2137), 1/16 degree 72-138 (-2 ... -3 %); with a displaced-pole quadrature in
+    // the launch 48-60 and as many helpers behind the compute roles (0.3145 -> 0.286)
+    if (pool < 0) pool = (int)env_long("OGG_PASS_LL_POOL", (light || points >= 16000000) ? 1 : 0);
+    s.pool = pool;
+    // shares of the 1/8 degree grid, pooled (same box, against the owned blocks at their own best counts): a half 96 resident workgroups
+    // (0.1012 -> 0.0962 ms), a quarter 96 (0.0572 -> 0.0561; the last rank of four 0.0663 -> 0.0597), an eighth 120 (0.0307 -> 0.0295);
+    // the 1/4 degree grid with its displaced-pole quadrature is better off with owned blocks (+1 ... +9 % pooled)
     long max_wg = alone ? 2048
-                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", light ? 156 : 90)
-                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", light ? 150 : 90)
-                                                                   : env_long("OGG_PASS_LL_WG_SMALL", (light && points >= 4000000) ? 180 : 120)));
+                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? 96 : 60) : (light ? 156 : 90))
+                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", pool ? 96 : (light ? 150 : 90))
+                                                                   : env_long("OGG_PASS_LL_WG_SMALL", points >= 4000000 ? (pool ? 96 : (light ? 180 : 120)) : 120)));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
     s.gy = gy < 1 ? 1 : gy;
@@ -383,7 +442,7 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         // `light`: mirrored caps and no displaced-pole quadrature in this launch (with one, the launch still carries enough arithmetic for
         // the strips to hide behind: 1/8 degree with the displaced pole 0.257 ms at 90 resident workgroups, 0.269 at 120, 0.285 at 150)
         const bool light = have_cap && ogg::cap_symmetry(cap->symmetry) && B.n_dquad == 0;
-        B.share = make_share(ll, s1, n_strips_ll, ni1, false, light);
+        B.share = make_share(ll, s1, n_strips_ll, ni1, false, light, have_quad ? -1 : 0);
         // helper workgroups for the lat-lon strips at the end of the launch (ogg_latlon_fused_dev.h): the claim counters live in the
         // bipolar cap's workspace and are zeroed by launch A with its tables
         // (measured: 1/8 degree whole grid 0.246 -> 0.237 ms, 1/16 degree 1.23 -> 1.19; half, a quarter, an eighth of the 1/8 degree grid
@@ -391,7 +450,12 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         // (mirrored caps: the compute roles drain early, helpers would join almost at once and only add writers -- measured 2-5 % slower
         // than none on three boxes: off)
         const long helpers = env_long("OGG_PASS_LL_HELPERS", (B.share.points >= 16000000 && !light) ? 2 : 0);
-        if (have_quad && helpers > 0 && B.share.n_wg > 0 && 2 * B.share.n_wg <= QUAD_LL_CLAIM_WORDS) {
+        if (B.share.pool && B.share.n_wg > 0 && B.share.gx <= QUAD_LL_CLAIM_WORDS) {
+            B.share.claims = qp.p.ll_claims;
+            B.share.n_help = B.share.n_wg * env_long("OGG_PASS_LL_POOL_HELPERS", light ? 0 : 1);
+        } else if (B.share.pool) {
+            B.share.pool = 0;
+        } else if (have_quad && helpers > 0 && B.share.n_wg > 0 && 2 * B.share.n_wg <= QUAD_LL_CLAIM_WORDS) {
             B.share.claims = qp.p.ll_claims;
             B.share.n_help = B.share.n_wg * helpers;
         }
