@@ -614,6 +614,24 @@ def main():
                                       cap_symmetry=(args.cap_symmetry == "mirror"))
         except Exception as exc:  # never lose the bench line over the secondary number
             dp_other = {"error": repr(exc)}
+    # what this box's write path gives a plain fill right now, in this process (after the timed region): the boxes of the pool differ by 20 %
+    # in what they sustain and one box moves by as much within minutes, so a launch's GB/s is best read beside it
+    fill_ref = None
+    if rank == 0 and args.as_rank is None:
+        try:
+            buf = torch.empty(1 << 27, dtype=torch.float64, device=device)   # 1 GiB
+            for _ in range(5):
+                buf.fill_(1.0)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(20):
+                buf.fill_(1.0)
+            ev1.record()
+            torch.cuda.synchronize()
+            fill_ref = round(20 * buf.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+            del buf
+        except Exception as exc:  # never lose the bench line over the reference
+            fill_ref = None
     power = None
     if args.power_probe > 0 and world == 1 and args.latlon == "fused" and args.as_rank is None:
         try:
@@ -680,10 +698,14 @@ def main():
                                       "other kernel sources than the loaded library's (`counters`)",
                     "limited_by": "fp64 VALU issue, not HBM (see roofline_valu)" if (vc and vc["valu_busy_frac"] > 0.6) else None,
                     "note": "longest of the launches of the fused pass; HIP events recorded by the library on the launch stream in "
-                            "%d passes of the timed region.  It carries lat-lon row strips (HBM-write bound) AND cap mesh / quadrature "
-                            "workgroups (fp64-VALU bound, DESIGN.md 4); with both active the socket sits at its power limit and the clock "
-                            "drops (`power`), so `frac` is what the WORKLOAD allows, not a statement about the write path.  `kernels` lists the "
-                            "stand-alone kernels, one after the other." % n_sampled}
+                            "%d passes right after the timed region.  It carries lat-lon row strips (HBM-write bound) AND cap mesh / "
+                            "quadrature workgroups (fp64 VALU; with mirrored cap columns a third of round 4's arithmetic): the launch is "
+                            "bound by its writes (DESIGN.md 4.1) unless `limited_by` says otherwise.  `plain_fill_GBps`: a 1 GiB "
+                            "torch fill_ timed in this process after the region -- what this box's write path gives ONE contiguous stream "
+                            "right now.  `kernels` lists the stand-alone kernels, one after the other." % n_sampled}
+            if fill_ref:
+                roof["plain_fill_GBps"] = fill_ref
+                roof["achieved_over_plain_fill"] = round(roof["achieved"] / fill_ref, 4)
             if vc:
                 # issue-time floor of the launch: every wave64 VALU instruction occupies its SIMD for >= 4 cycles (quarter-rate fp64
                 # rcp/rsq/sqrt: 16), 1024 SIMDs, at the clock the counter run held

@@ -304,6 +304,7 @@ inline int plan_latlon(int n_bands, const ogg_latlon_band* bands, long ni1, doub
     const long gx = latlon_gx(ni1);
     long rpb = (total_rows * gx + 2047) / 2048;  // aim at >= 2048 row strips x column tiles
     rpb = rpb < 8 ? 8 : (rpb > LF_ROWS ? LF_ROWS : rpb);   // >= 8 rows per strip: the per-strip set-up (row scalars, two barriers) is worth ~2 rows
+    if (const char* e = getenv("OGG_LL_ROWS_PER_STRIP")) rpb = atol(e) < 1 ? 1 : (atol(e) > LF_ROWS ? LF_ROWS : atol(e));   // (experiments)
     p.strip0[0] = 0;
     for (int k = 0; k < p.n_bands; ++k) p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
     p.ni1 = ni1, p.lon0 = lon0, p.lenlon = lenlon, p.Ni = (double)(ni1 - 1);

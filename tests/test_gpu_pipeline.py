@@ -340,12 +340,12 @@ def test_pass_does_not_depend_on_tiling_knobs(sg, name, dp_arc, monkeypatch):
     plan = sg.SupergridPlan(dp_arc=dp_arc, **CONFIGS[name])
     base = run_pass_mode(sg, plan, 1)
     knobs = ({"OGG_QUAD_TARGET_WAVES": "1", "OGG_DPQUAD_TARGET_WAVES": "1", "OGG_MESH_ROWS": "32", "OGG_DPMESH_ROWS": "1",
-              "OGG_PASS_LL_WG": "7", "OGG_PASS_LL_WG_MID": "7", "OGG_PASS_LL_WG_SMALL": "7", "OGG_PASS_ORDER": "43210", "OGG_PASS_LL_NT": "0", "OGG_PASS_LL_HELPERS": "0", "OGG_PASS_LL_POOL": "1"},
+              "OGG_PASS_LL_WG": "7", "OGG_PASS_LL_WG_MID": "7", "OGG_PASS_LL_WG_SMALL": "7", "OGG_PASS_ORDER": "43210", "OGG_PASS_LL_NT": "0", "OGG_PASS_LL_HELPERS": "0", "OGG_PASS_LL_POOL": "1", "OGG_LL_ROWS_PER_STRIP": "5"},
              {"OGG_QUAD_TARGET_WAVES": "1000000", "OGG_DPQUAD_TARGET_WAVES": "1000000", "OGG_MESH_ROWS": "1", "OGG_DPMESH_ROWS": "3",
               "OGG_PASS_LL_WG": "1000", "OGG_PASS_LL_WG_MID": "1000", "OGG_PASS_LL_WG_SMALL": "1000", "OGG_PASS_ORDER": "01234",
               "OGG_PASS_LL_HELPERS": "5", "OGG_BP_ROW_COST": "2,1.5,3", "OGG_TOP_RANK_TAIL_US": "20"},
              {"OGG_QUAD_TARGET_WAVES": "300", "OGG_DPQUAD_TARGET_WAVES": "200", "OGG_MESH_ROWS": "5", "OGG_DPMESH_ROWS": "5",
-              "OGG_PASS_LL_POOL": "1", "OGG_PASS_LL_POOL_HELPERS": "2", "OGG_PASS_LL_WG_SMALL": "40"})
+              "OGG_PASS_LL_POOL": "1", "OGG_PASS_LL_POOL_HELPERS": "2", "OGG_PASS_LL_WG_SMALL": "40", "OGG_LL_ROWS_PER_STRIP": "32"})
     for world, kn in zip((1, 3, 2), knobs):
         for k, v in kn.items():
             monkeypatch.setenv(k, v)
