@@ -24,6 +24,7 @@ torch is used for device memory, streams, graphs and torch.distributed only; eve
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -38,22 +39,26 @@ def band(n_rows, rank, world):
     return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
 
 
-def band_weighted(cost, rank, world, top_capacity=1.0):
+def band_weighted(cost, rank, world, top_capacity=1.0, capacities=None):
     """Contiguous rows [lo, hi) of `rank` such that every rank gets about the same total cost; `cost` is the per-row
     cost array.  ``top_capacity``: the share of the LAST rank relative to the others' (it carries a fixed extra launch, the
     literal fix-up of the bipolar quadrature, and so takes a smaller share of EVERY sub-grid: the lat-lon strips and the cap
-    workgroups of a rank finish together, so shortening one of them alone shortens nothing).  The boundaries are a function
-    of (cost, world, top_capacity) only, identical on every rank."""
+    workgroups of a rank finish together, so shortening one of them alone shortens nothing).  ``capacities``: one relative share
+    per rank instead (refine_split: what every rank measured on its own GPU).  The boundaries are a function of (cost, world,
+    top_capacity or capacities) only, identical on every rank."""
     c = np.concatenate(([0.0], np.cumsum(np.asarray(cost, dtype=np.float64))))
     total = c[-1]
-    capacity = (world - 1) + top_capacity
+    caps = [1.0] * (world - 1) + [float(top_capacity)] if capacities is None else [float(v) for v in capacities]
+    if len(caps) != world or min(caps) <= 0.0:
+        raise ValueError("band_weighted: %d capacities for %d ranks (all must be positive)" % (len(caps), world))
+    before = np.concatenate(([0.0], np.cumsum(caps)))
 
     def edge(r):
         if r <= 0:
             return 0
         if r >= world:
             return len(cost)
-        return int(np.searchsorted(c, total * r / capacity, side="left"))
+        return int(np.searchsorted(c, total * before[r] / before[-1], side="left"))
 
     return edge(rank), edge(rank + 1)
 
@@ -180,6 +185,9 @@ class SupergridPlan(object):
                 w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
                 bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
                 bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
+                # first cell row the kernels evaluate with the guard (plan_quad, csrc/ogg_bipolar_dev.h: the same expression); a band that ends
+                # at or below it has no guarded rows and hence no fix-up launch (rows_of snaps the last boundary to it when it is close)
+                bp.guard_row0 = min(max(int(math.floor(Nj_ncap * (guard_lat - float(lat0_bp)) / (90.0 - float(lat0_bp)))) - 1, 0), Nj_ncap)
         # ---- Southern Ocean (OGG:1080-1103); like the reference this needs the Mercator sub-grid
         lat0_SO = -78.0
         if south_ocean_lower_lat > -90:
@@ -257,16 +265,18 @@ class SupergridPlan(object):
 
     split_times = None
 
-    def set_split_times(self, tail_us, pass_us, source, top_capacity=None):
+    def set_split_times(self, tail_us, pass_us, source, top_capacity=None, rank_capacity=None):
         """What the band split takes the last rank's share from (rows_of).  The MODEL: `tail_us`, what the bipolar quadrature's fix-up
         launch -- which only the rank with the top rows runs -- adds to that rank's pass, and `pass_us`, one pass of the whole grid on
         one GPU: share of the last rank = 1 - world * tail_us / pass_us of the others'.  A MEASURED share (`top_capacity`, from
         calibrate_split) takes precedence for the world size it was measured at.  The same values on every rank give the same edges."""
         for s in self.subs:
-            s.tail_us, s.pass_us, s.top_capacity = float(tail_us), float(pass_us), top_capacity
+            s.tail_us, s.pass_us, s.top_capacity, s.rank_capacity = float(tail_us), float(pass_us), top_capacity, rank_capacity
         self.split_times = {"tail_us": float(tail_us), "pass_us": float(pass_us), "source": source}
         if top_capacity is not None:
             self.split_times["top_capacity"] = {"world": int(top_capacity[0]), "share_of_last_rank": float(top_capacity[1])}
+        if rank_capacity is not None:   # (refine_split: one relative share per rank; takes precedence for its world size)
+            self.split_times["rank_capacity"] = {"world": int(rank_capacity[0]), "shares": [float(v) for v in rank_capacity[1]]}
 
     def calibrate_split(self, device, rank=0, world=1, passes=40, broadcast=True, force=False, rounds=5):
         """Replace the fitted split constants by a measurement on THIS box, before any band buffer exists (rank 0 alone works, about a
@@ -364,29 +374,51 @@ class SupergridPlan(object):
         """One rebalancing step from what every rank measured on its OWN GPU under the current split, all ranks running at once (the
         conditions of the job: calibrate_split times the shares one after the other on rank 0's idle chip).  ``per_rank_us``: every
         rank's time per pass in rank order -- the same list on every rank (bench.py all-gathers it), so every rank derives the same new
-        edges and nothing is broadcast.  The last rank's share is scaled by mean(T of the others) / T_last; inside the ``deadband`` (the
-        last rank within 3 % of the others: a timing cannot tell) the split stays.  Returns True when the split changed (band buffers must
-        be rebuilt).  The measured times and both shares are recorded in ``split_times["self_calibration"]``."""
+        edges and nothing is broadcast.  Every rank's share is scaled by mean(T) / T_rank (a rank whose rows cost more than the cost
+        model says -- the rows next to the guarded ones, a GPU of the slower write-path class -- gets fewer); inside the ``deadband``
+        (every rank within 3 % of the mean: a timing cannot tell) the split stays.  Returns True when the split changed (band buffers
+        must be rebuilt).  The measured times and the shares before and after are recorded in ``split_times["self_calibration"]``."""
         if world <= 1 or self.split_times is None or len(per_rank_us) != world:
             return False
         t = [float(v) for v in per_rank_us]
-        others = sum(t[:-1]) / (world - 1)
+        if min(t) <= 0.0:
+            return False
+        caps_old = self.rank_capacities(world)
+        mean = sum(t) / world
+        worst = max(abs(v / mean - 1.0) for v in t)
+        rec = {"world": world, "per_rank_us": [round(v, 3) for v in t], "shares_before": [round(c, 5) for c in caps_old],
+               "share_of_last_rank_before": caps_old[-1] / caps_old[0], "others_over_last": (sum(t[:-1]) / (world - 1)) / t[-1],
+               "largest_deviation_from_mean": worst}
+        changed = worst > deadband
+        caps_new = caps_old
+        if changed:
+            caps_new = [min(max(c * mean / v, 0.3 * c), 1.5 * c) for c, v in zip(caps_old, t)]
+            norm = caps_new[0]
+            caps_new = [c / norm for c in caps_new]     # (relative shares: rank 0 = 1, as before)
+        rec["shares_after"] = [round(c, 5) for c in caps_new]
+        rec["share_of_last_rank_after"] = caps_new[-1] / caps_new[0]
+        hist = list(self.split_times.get("self_calibration", []))
+        self.set_split_times(self.split_times["tail_us"], self.split_times["pass_us"], self.split_times["source"],
+                             top_capacity=(world, caps_new[-1] / caps_new[0]), rank_capacity=((world, caps_new) if changed else self._rank_capacity()))
+        self.split_times["self_calibration"] = hist + [rec]
+        return changed
+
+    def _rank_capacity(self):
+        return getattr(self.subs[0], "rank_capacity", None)
+
+    def rank_capacities(self, world):
+        """Relative shares of the ranks under the current split (rank 0 = 1 unless refine_split has set them)."""
         s0 = self.subs[0]
+        rc = getattr(s0, "rank_capacity", None)
+        if rc is not None and int(rc[0]) == world:
+            return [float(v) for v in rc[1]]
         old = getattr(s0, "top_capacity", None)
         if old is not None and int(old[0]) == world:
-            cap_old = float(old[1])
+            cap = float(old[1])
         else:
             tail, whole = self.split_times["tail_us"], self.split_times["pass_us"]
-            cap_old = min(1.0, 1.0 - world * tail / whole) if (whole > 0 and world * tail / whole <= 0.5) else 1.0
-        ratio = others / t[-1] if t[-1] > 0 else 1.0
-        rec = {"world": world, "per_rank_us": [round(v, 3) for v in t], "share_of_last_rank_before": cap_old, "others_over_last": ratio}
-        changed = abs(ratio - 1.0) > deadband
-        cap_new = min(max(cap_old * ratio, 0.3), 1.3) if changed else cap_old
-        rec["share_of_last_rank_after"] = cap_new
-        hist = list(self.split_times.get("self_calibration", []))
-        self.set_split_times(self.split_times["tail_us"], self.split_times["pass_us"], self.split_times["source"], top_capacity=(world, cap_new))
-        self.split_times["self_calibration"] = hist + [rec]
-        return changed and cap_new != cap_old
+            cap = min(1.0, 1.0 - world * tail / whole) if (whole > 0 and world * tail / whole <= 0.5) else 1.0
+        return [1.0] * (world - 1) + [cap]
 
     def south_cut(self, sc_y0=None):
         """(rows cut from the southern cap, rows cut from the Southern Ocean piece, cap removed) by --south_cutoff_row / _ang,
@@ -508,6 +540,33 @@ class Supergrid(object):
         """Point rows [lo, hi) of sub-grid `s` owned by `rank`: equal row counts, or equal cost where rows differ in cost; the
         last rank's share of every sub-grid is smaller by what the fix-up launch costs it (SubGridPlan.tail_us / pass_us, set by
         SupergridPlan when the grid has a bipolar cap with metrics)."""
+        cost = getattr(s, "row_cost", None)
+        tail_us, pass_us = getattr(s, "tail_us", 0.0), getattr(s, "pass_us", 0.0)
+        measured = getattr(s, "top_capacity", None)
+        per_rank = getattr(s, "rank_capacity", None)
+        if world > 1 and per_rank is not None and int(per_rank[0]) == world:   # every rank's share as refine_split rebalanced them
+            return Supergrid._snap_to_guard(s, rank, world, lambda r: band_weighted(np.ones(s.nj1) if cost is None else cost, r, world,
+                                                                                    capacities=per_rank[1]))
+        return Supergrid._snap_to_guard(s, rank, world, lambda r: Supergrid._rows_of_unsnapped(s, r, world))
+
+    @staticmethod
+    def _snap_to_guard(s, rank, world, rows):
+        """The boundary between the last two ranks of the bipolar cap, moved DOWN to the first guarded row when it lies a little above
+        it: a rank that holds a sliver of the guarded rows runs the guarded role and the fix-up launch for it (the second-to-last
+        rank of eight at 1/8 degree: 11 of its 127 cap rows, +2.5 us on a 31 us pass), the last rank runs both anyway.  'A little':
+        at most a quarter of a rank's nominal rows.  ``rows(r)``: the unsnapped [lo, hi) of rank r."""
+        lo, hi = rows(rank)
+        g = getattr(s, "guard_row0", None)
+        if g is None or world < 2 or rank < world - 2 or os.environ.get("OGG_SPLIT_SNAP_GUARD", "1") == "0":
+            return lo, hi
+        e = rows(world - 1)[0]            # first point row of the last rank
+        g = max(g - 1, 0)                 # one row of margin: the kernels' own threshold must not be met by rounding
+        if not (0 < e - g <= 0.25 * s.nj1 / world) or g <= rows(world - 2)[0]:
+            return lo, hi
+        return (lo, g) if rank == world - 2 else (g, hi)
+
+    @staticmethod
+    def _rows_of_unsnapped(s, rank, world):
         cost = getattr(s, "row_cost", None)
         tail_us, pass_us = getattr(s, "tail_us", 0.0), getattr(s, "pass_us", 0.0)
         measured = getattr(s, "top_capacity", None)

@@ -229,8 +229,8 @@ def _refine_worker(rank, world, port, q):
 
 def test_every_rank_rebalances_the_split_from_the_gathered_times():
     """Per-rank self-calibration (bench.py at N > 1): the ranks all-gather their own times per pass and each applies
-    SupergridPlan.refine_split to the same list -- the same new edges on every rank, the last rank's share scaled by
-    mean(others) / T_last, every row still covered once; inside the dead band nothing moves."""
+    SupergridPlan.refine_split to the same list -- the same new edges on every rank, every rank's share scaled by mean(T) / T_rank
+    (relative to rank 0's), every row still covered once; inside the dead band nothing moves."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -245,7 +245,8 @@ def test_every_rank_rebalances_the_split_from_the_gathered_times():
     assert all(r[1] for r in res) and res[0][2:] == res[1][2:] == res[2][2:]
     rec = res[0][4]
     assert rec["per_rank_us"] == [40.0, 41.0, 50.0] and rec["share_of_last_rank_before"] == 0.9
-    assert abs(rec["share_of_last_rank_after"] - 0.9 * 40.5 / 50.0) < 1e-12
+    assert abs(rec["share_of_last_rank_after"] - 0.9 * 40.0 / 50.0) < 1e-12
+    assert np.allclose(rec["shares_after"], [1.0, 40.0 / 41.0, 0.9 * 40.0 / 50.0], atol=1e-5) and rec["shares_before"] == [1.0, 1.0, 0.9]
     import ocean_model_grid_generator_amd.supergrid as sg_mod
     plan = _plan(sg_mod, 2)
     plan.set_split_times(6.0, 120.0, "test", top_capacity=(3, 0.9))
@@ -271,7 +272,61 @@ def test_every_rank_rebalances_the_split_from_the_gathered_times():
             lo, hi = sg_mod.Supergrid.rows_of(s, k, 8)
             rows += list(range(lo, hi))
         assert rows == list(range(s.nj1)), s.name
+    # a rank in the MIDDLE that is slower than the cost model says (the rows under the guarded ones: 34.3 us against 31.6 in the
+    # one-GPU rehearsal of the 1/8 degree grid) hands rows to the others; a second step from balanced times changes nothing
+    plan8 = _plan(sg_mod, 8)
+    plan8.set_split_times(6.5, 192.0, "test", top_capacity=(8, 0.8))
+    merc8 = next(s for s in plan8.subs if s.name == "Merc")
+    n6 = np.diff(sg_mod.Supergrid.rows_of(merc8, 6, 8))[0]
+    n7 = np.diff(sg_mod.Supergrid.rows_of(merc8, 7, 8))[0]
+    assert plan8.refine_split([30.4, 31.7, 31.7, 31.6, 31.7, 31.6, 34.3, 31.6], 8)
+    assert np.diff(sg_mod.Supergrid.rows_of(merc8, 6, 8))[0] < n6 and abs(np.diff(sg_mod.Supergrid.rows_of(merc8, 7, 8))[0] - n7) <= 0.02 * n7
+    assert plan8.split_times["rank_capacity"]["world"] == 8 and len(plan8.split_times["rank_capacity"]["shares"]) == 8
+    for s in plan8.subs:
+        rows = []
+        for k in range(8):
+            lo, hi = sg_mod.Supergrid.rows_of(s, k, 8)
+            rows += list(range(lo, hi))
+        assert rows == list(range(s.nj1)), s.name
+    shares = list(plan8.split_times["rank_capacity"]["shares"])
+    assert not plan8.refine_split([31.8, 31.9, 31.7, 31.8, 31.9, 31.8, 32.0, 31.7], 8)
+    assert plan8.split_times["rank_capacity"]["shares"] == shares
     # within 3 %: the split stays (and the record says so)
     assert not plan.refine_split([40.0, 41.0, 41.2], 3)
     assert plan.split_times["self_calibration"][-1]["share_of_last_rank_after"] == plan.split_times["self_calibration"][-1]["share_of_last_rank_before"]
     assert len(plan.split_times["self_calibration"]) == 2
+
+
+def test_last_boundary_of_the_cap_snaps_to_the_first_guarded_row(monkeypatch):
+    """A rank that would hold a sliver of the cap's guarded rows (the second-to-last of eight at 1/8 degree with the measured share of
+    the last rank: 11 of its 127 cap rows) would run the guarded role and the fix-up launch for them: the boundary between the last two
+    ranks moves down to the first guarded row instead.  Only when it is close, only in the cap, every row still owned once."""
+    import ocean_model_grid_generator_amd.supergrid as sg_mod
+    plan = _plan(sg_mod, 8)
+    plan.set_split_times(4.81, 215.1, "test", top_capacity=(8, 0.5808))
+    bp = next(s for s in plan.subs if s.kind == "bipolar")
+    assert bp.guard_row0 == 892            # plan_quad's jg for K = 4000 at Nj = 960, lat0_bp = 64.0589...: floor(960 (88.188 - lat0) / (90 - lat0)) - 1
+    monkeypatch.setenv("OGG_SPLIT_SNAP_GUARD", "0")
+    lo6, hi6 = sg_mod.Supergrid.rows_of(bp, 6, 8)
+    assert bp.guard_row0 < hi6 <= bp.guard_row0 + 30        # unsnapped: a few guarded rows in rank 6
+    monkeypatch.delenv("OGG_SPLIT_SNAP_GUARD")
+    assert sg_mod.Supergrid.rows_of(bp, 6, 8) == (lo6, bp.guard_row0 - 1)
+    assert sg_mod.Supergrid.rows_of(bp, 7, 8) == (bp.guard_row0 - 1, bp.nj1)
+    assert sg_mod.Supergrid.rows_of(bp, 5, 8)[1] == lo6
+    for s in plan.subs:
+        rows = []
+        for k in range(8):
+            lo, hi = sg_mod.Supergrid.rows_of(s, k, 8)
+            rows += list(range(lo, hi))
+        assert rows == list(range(s.nj1)), s.name
+        if s.kind != "bipolar":       # the other sub-grids keep their edges
+            monkeypatch.setenv("OGG_SPLIT_SNAP_GUARD", "0")
+            ref = [sg_mod.Supergrid.rows_of(s, k, 8) for k in range(8)]
+            monkeypatch.delenv("OGG_SPLIT_SNAP_GUARD")
+            assert ref == [sg_mod.Supergrid.rows_of(s, k, 8) for k in range(8)]
+    # four ranks: the last boundary lies far below the guarded rows -- nothing moves; and after a rebalancing step the snap still holds
+    plan.set_split_times(4.81, 215.1, "test", top_capacity=(4, 0.8))
+    assert sg_mod.Supergrid.rows_of(bp, 3, 4)[0] < bp.guard_row0 - 1
+    plan.set_split_times(4.81, 215.1, "test", top_capacity=(8, 0.5808))
+    assert plan.refine_split([30.5, 31.0, 30.9, 31.0, 30.9, 30.9, 33.6, 31.9], 8)
+    assert sg_mod.Supergrid.rows_of(bp, 6, 8)[1] == bp.guard_row0 - 1 == sg_mod.Supergrid.rows_of(bp, 7, 8)[0]
