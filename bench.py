@@ -440,8 +440,9 @@ def main():
                 sg.run_pass()
             torch.cuda.synchronize()
     # Several ranks: every rank times its OWN share on its own GPU, all at once (the job's conditions; calibrate_split timed the shares one
-    # after the other on rank 0's idle chip), the times are all-gathered, and ONE rebalancing step scales the last rank's share -- the
-    # same arithmetic on the same list on every rank, hence the same edges.  A second measurement under the new split is recorded too.
+    # after the other on rank 0's idle chip), the times are all-gathered, and up to two rebalancing steps scale every rank's share by
+    # mean(T) / T_rank -- the same arithmetic on the same list on every rank, hence the same edges.  Every step is measured again; one that
+    # made the slowest rank slower is taken back.
     if args.latlon == "fused" and world > 1 and args.as_rank is None and os.environ.get("OGG_SPLIT_SELF_CALIBRATE", "1") != "0":
         def own_us(n=200):
             sync()
@@ -453,14 +454,35 @@ def main():
             gathered = [None] * world
             dist.all_gather_object(gathered, mine)
             return gathered
-        if plan.refine_split(own_us(), world):
-            sg.close()
-            sg = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
-            sg.overlap, sg.launch = bool(args.overlap), "pass"
+
+        def rebuild():
+            g = supergrid.Supergrid(plan, rank=rank, world=world, device=device, halo=args.halo, latlon=args.latlon)
+            g.overlap, g.launch = bool(args.overlap), "pass"
             for _ in range(100):
-                sg.run_pass()
+                g.run_pass()
             torch.cuda.synchronize()
-            plan.split_times["self_calibration"][-1]["per_rank_us_after"] = [round(v, 3) for v in own_us()]
+            return g
+
+        before = own_us()
+        for _ in range(2):
+            kept = (getattr(plan.subs[0], "top_capacity", None), getattr(plan.subs[0], "rank_capacity", None))
+            if not plan.refine_split(before, world):
+                break
+            sg.close()
+            sg = rebuild()
+            after = own_us()
+            rec = plan.split_times["self_calibration"][-1]
+            rec["per_rank_us_after"] = [round(v, 3) for v in after]
+            if max(after) > 1.01 * max(before):
+                hist = plan.split_times["self_calibration"]
+                plan.set_split_times(plan.split_times["tail_us"], plan.split_times["pass_us"], plan.split_times["source"],
+                                     top_capacity=kept[0], rank_capacity=kept[1])
+                rec["taken_back"] = True
+                plan.split_times["self_calibration"] = hist
+                sg.close()
+                sg = rebuild()
+                break
+            before = after
     sg.launch = "kernels"
     can_graph = not (world > 1 and args.latlon == "stencil" and args.halo == "rccl")
     use_graph = bool(args.graph) and can_graph

@@ -185,9 +185,6 @@ class SupergridPlan(object):
                 w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
                 bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))
                 bp.row_cost[-1] += lump   # the tail launch (fix-up + j = ny row) only the top band runs, in plain-row equivalents
-                # first cell row the kernels evaluate with the guard (plan_quad, csrc/ogg_bipolar_dev.h: the same expression); a band that ends
-                # at or below it has no guarded rows and hence no fix-up launch (rows_of snaps the last boundary to it when it is close)
-                bp.guard_row0 = min(max(int(math.floor(Nj_ncap * (guard_lat - float(lat0_bp)) / (90.0 - float(lat0_bp)))) - 1, 0), Nj_ncap)
         # ---- Southern Ocean (OGG:1080-1103); like the reference this needs the Mercator sub-grid
         lat0_SO = -78.0
         if south_ocean_lower_lat > -90:
@@ -545,31 +542,7 @@ class Supergrid(object):
         measured = getattr(s, "top_capacity", None)
         per_rank = getattr(s, "rank_capacity", None)
         if world > 1 and per_rank is not None and int(per_rank[0]) == world:   # every rank's share as refine_split rebalanced them
-            return Supergrid._snap_to_guard(s, rank, world, lambda r: band_weighted(np.ones(s.nj1) if cost is None else cost, r, world,
-                                                                                    capacities=per_rank[1]))
-        return Supergrid._snap_to_guard(s, rank, world, lambda r: Supergrid._rows_of_unsnapped(s, r, world))
-
-    @staticmethod
-    def _snap_to_guard(s, rank, world, rows):
-        """The boundary between the last two ranks of the bipolar cap, moved DOWN to the first guarded row when it lies a little above
-        it: a rank that holds a sliver of the guarded rows runs the guarded role and the fix-up launch for it (the second-to-last
-        rank of eight at 1/8 degree: 11 of its 127 cap rows, +2.5 us on a 31 us pass), the last rank runs both anyway.  'A little':
-        at most a quarter of a rank's nominal rows.  ``rows(r)``: the unsnapped [lo, hi) of rank r."""
-        lo, hi = rows(rank)
-        g = getattr(s, "guard_row0", None)
-        if g is None or world < 2 or rank < world - 2 or os.environ.get("OGG_SPLIT_SNAP_GUARD", "1") == "0":
-            return lo, hi
-        e = rows(world - 1)[0]            # first point row of the last rank
-        g = max(g - 1, 0)                 # one row of margin: the kernels' own threshold must not be met by rounding
-        if not (0 < e - g <= 0.25 * s.nj1 / world) or g <= rows(world - 2)[0]:
-            return lo, hi
-        return (lo, g) if rank == world - 2 else (g, hi)
-
-    @staticmethod
-    def _rows_of_unsnapped(s, rank, world):
-        cost = getattr(s, "row_cost", None)
-        tail_us, pass_us = getattr(s, "tail_us", 0.0), getattr(s, "pass_us", 0.0)
-        measured = getattr(s, "top_capacity", None)
+            return band_weighted(np.ones(s.nj1) if cost is None else cost, rank, world, capacities=per_rank[1])
         cap = 1.0
         if world > 1 and measured is not None and int(measured[0]) == world:
             cap = float(measured[1])        # the last rank's share as calibrate_split measured it for this world size

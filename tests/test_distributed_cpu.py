@@ -296,37 +296,3 @@ def test_every_rank_rebalances_the_split_from_the_gathered_times():
     assert plan.split_times["self_calibration"][-1]["share_of_last_rank_after"] == plan.split_times["self_calibration"][-1]["share_of_last_rank_before"]
     assert len(plan.split_times["self_calibration"]) == 2
 
-
-def test_last_boundary_of_the_cap_snaps_to_the_first_guarded_row(monkeypatch):
-    """A rank that would hold a sliver of the cap's guarded rows (the second-to-last of eight at 1/8 degree with the measured share of
-    the last rank: 11 of its 127 cap rows) would run the guarded role and the fix-up launch for them: the boundary between the last two
-    ranks moves down to the first guarded row instead.  Only when it is close, only in the cap, every row still owned once."""
-    import ocean_model_grid_generator_amd.supergrid as sg_mod
-    plan = _plan(sg_mod, 8)
-    plan.set_split_times(4.81, 215.1, "test", top_capacity=(8, 0.5808))
-    bp = next(s for s in plan.subs if s.kind == "bipolar")
-    assert bp.guard_row0 == 892            # plan_quad's jg for K = 4000 at Nj = 960, lat0_bp = 64.0589...: floor(960 (88.188 - lat0) / (90 - lat0)) - 1
-    monkeypatch.setenv("OGG_SPLIT_SNAP_GUARD", "0")
-    lo6, hi6 = sg_mod.Supergrid.rows_of(bp, 6, 8)
-    assert bp.guard_row0 < hi6 <= bp.guard_row0 + 30        # unsnapped: a few guarded rows in rank 6
-    monkeypatch.delenv("OGG_SPLIT_SNAP_GUARD")
-    assert sg_mod.Supergrid.rows_of(bp, 6, 8) == (lo6, bp.guard_row0 - 1)
-    assert sg_mod.Supergrid.rows_of(bp, 7, 8) == (bp.guard_row0 - 1, bp.nj1)
-    assert sg_mod.Supergrid.rows_of(bp, 5, 8)[1] == lo6
-    for s in plan.subs:
-        rows = []
-        for k in range(8):
-            lo, hi = sg_mod.Supergrid.rows_of(s, k, 8)
-            rows += list(range(lo, hi))
-        assert rows == list(range(s.nj1)), s.name
-        if s.kind != "bipolar":       # the other sub-grids keep their edges
-            monkeypatch.setenv("OGG_SPLIT_SNAP_GUARD", "0")
-            ref = [sg_mod.Supergrid.rows_of(s, k, 8) for k in range(8)]
-            monkeypatch.delenv("OGG_SPLIT_SNAP_GUARD")
-            assert ref == [sg_mod.Supergrid.rows_of(s, k, 8) for k in range(8)]
-    # four ranks: the last boundary lies far below the guarded rows -- nothing moves; and after a rebalancing step the snap still holds
-    plan.set_split_times(4.81, 215.1, "test", top_capacity=(4, 0.8))
-    assert sg_mod.Supergrid.rows_of(bp, 3, 4)[0] < bp.guard_row0 - 1
-    plan.set_split_times(4.81, 215.1, "test", top_capacity=(8, 0.5808))
-    assert plan.refine_split([30.5, 31.0, 30.9, 31.0, 30.9, 30.9, 33.6, 31.9], 8)
-    assert sg_mod.Supergrid.rows_of(bp, 6, 8)[1] == bp.guard_row0 - 1 == sg_mod.Supergrid.rows_of(bp, 7, 8)[0]

@@ -85,6 +85,7 @@ def test_n_ranks_rehearsed_on_one_gpu(n, workload):
     # ... refined by every rank's own timing of its own share (all-gathered; one rebalancing step): the record holds every rank's time
     sc = bs["self_calibration"]
     assert len(sc) >= 1 and sc[0]["world"] == n and len(sc[0]["per_rank_us"]) == n and all(t > 0 for t in sc[0]["per_rank_us"])
+    assert len(sc[0]["shares_before"]) == n == len(sc[0]["shares_after"]) and all(0.1 < v < 3.0 for v in sc[0]["shares_after"])
     assert bs["top_capacity"]["world"] == n and 0.3 <= bs["top_capacity"]["share_of_last_rank"] <= 1.3
     assert len(many["per_rank"]) == n
     assert one["band_split"] is None or "fitted constants" in one["band_split"]["source"]
