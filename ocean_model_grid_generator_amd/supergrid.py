@@ -181,6 +181,9 @@ class SupergridPlan(object):
                 lat_rows = lat0_bp + (np.arange(Nj_ncap + 1) + 1.0) * (90.0 - lat0_bp) / Nj_ncap   # top edge of each cell row
                 guard_lat = math.degrees(math.acos(2.0 / math.sqrt(K)))
                 fix_lat = math.degrees(math.acos(1.0 / math.sqrt(K)))
+                # (With the cap's columns mirrored a guarded row costs 1.3 / 0.33 = 4 plain ones in arithmetic; weights of 3, 4 and 5 were
+                # swept on the 8-way split of the 1/8 degree grid, one GPU: slowest rank 31.6 / 33.6 / 32.7 us against 31.7 with 1.3 and
+                # the per-rank rebalancing step -- more ranks get guarded rows and each pays the fix-up launch.  1.3 stays.)
                 w = [float(v) for v in os.environ.get("OGG_BP_ROW_COST", "1.3,1.3,0").split(",")]
                 w_fix, w_guard, lump = w[0], w[1], (w[2] if len(w) > 2 else 0.0)
                 bp.row_cost = np.where(lat_rows >= fix_lat, w_fix, np.where(lat_rows >= guard_lat, w_guard, 1.0))

@@ -21,6 +21,7 @@ ap.add_argument("--workload", default="r8")
 ap.add_argument("--config", action="append", default=[])
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--strips", action="store_true")
+ap.add_argument("--calibrate", action="store_true", help="the band split bench.py uses (calibrate_split on this box) instead of the fitted constants")
 ap.add_argument("--as-rank", type=int, default=0)
 ap.add_argument("--as-world", type=int, default=1)
 args = ap.parse_args()
@@ -29,6 +30,9 @@ tl = lib.ogg_timeline
 lib.ogg_timeline_strips.argtypes, lib.ogg_timeline_strips.restype = [ctypes.POINTER(ctypes.c_ulonglong)], ctypes.c_int
 tl.argtypes, tl.restype = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int], ctypes.c_int
 plan = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
+if args.calibrate and args.as_world > 1:
+    plan.calibrate_split("cuda:0", rank=0, world=args.as_world, broadcast=False)
+    print("split:", plan.split_times.get("top_capacity"), {s.name: supergrid.Supergrid.rows_of(s, args.as_rank, args.as_world) for s in plan.subs})
 sg = supergrid.Supergrid(plan, rank=args.as_rank, world=args.as_world, device="cuda:0", halo="recompute")
 sg.launch = "pass"
 for _ in range(100):

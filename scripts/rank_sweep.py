@@ -16,7 +16,7 @@ from ocean_model_grid_generator_amd import supergrid  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--workload", default="r8")
-ap.add_argument("--cost", nargs="*", default=["1.3,1.3,0"])
+ap.add_argument("--cost", nargs="*", default=["default"], help="OGG_BP_ROW_COST values to sweep (fix,guard,lump); `default`: the plan's own weights")
 ap.add_argument("--rounds", type=int, default=2, help="every rank is timed this many times (forwards, then backwards, ...); the best time counts")
 ap.add_argument("--dp-arc", default="chord")
 ap.add_argument("--json", default=None, help="append one JSON line per (world, cost) to this file")
@@ -26,7 +26,10 @@ ap.add_argument("--refine", type=int, default=1, help="after the first sweep, on
 ap.add_argument("--events", type=int, default=0, help="also print every rank's launch durations (HIP events around the launches of 20 extra passes)")
 args = ap.parse_args()
 for cost in args.cost:
-    os.environ["OGG_BP_ROW_COST"] = cost
+    if cost == "default":
+        os.environ.pop("OGG_BP_ROW_COST", None)
+    else:
+        os.environ["OGG_BP_ROW_COST"] = cost
     plan = supergrid.SupergridPlan(dp_arc=args.dp_arc, **bench.WORKLOADS[args.workload])
     if os.environ.get("OGG_SPLIT_CALIBRATE", "1") != "0":   # the split bench.py uses: tail / pass timed on this box (one process: no broadcast)
         plan.calibrate_split("cuda:0", rank=0, world=args.world, broadcast=False)
