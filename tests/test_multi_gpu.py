@@ -59,13 +59,14 @@ def test_two_ranks_reproduce_one_gpu_bitwise(extra):
     assert two["config"]["cells"] == one["config"]["cells"]
 
 
-@pytest.mark.parametrize("n,workload", [(2, "r2"), (4, "r4_om4"), (5, "r8")])
+@pytest.mark.parametrize("n,workload", [(2, "r2"), (4, "r4_om4"), (4, "r8")])
 def test_n_ranks_rehearsed_on_one_gpu(n, workload):
     """The whole N-rank run of bench.py on a box with ONE GPU (OGG_BENCH_ONE_GPU=1: every rank on cuda:0, the collectives over gloo
     because RCCL does not put two ranks on one device): the plain invocation starts its ranks, every rank takes its bands, barriers,
     the max-over-ranks reduction, the self-check's and the fingerprints' all-reduce, the gathered per-rank lines, ONE JSON line --
-    and the fingerprints of the band-sharded fields equal the single-GPU ones bit for bit.  (Five ranks is the most a one-GPU box of
-    this pool allows: six processes on the card, this one included; the 8-rank split itself is covered without processes in
+    and the fingerprints of the band-sharded fields equal the single-GPU ones bit for bit.  (Four ranks: a one-GPU box of this pool
+    allows six processes on the card, this one included, and kills the whole run at the seventh -- a five-rank case passed three times
+    and was killed the fourth, so one slot stays free; the 8-rank split itself is covered without processes in
     tests/test_distributed_cpu.py and rehearsed share by share by scripts/rank_sweep.py.)"""
     one = _bench(1, ["--workload", workload, "--power-probe", "0"])
     many = _bench(n, ["--workload", workload, "--power-probe", "0"], {"OGG_BENCH_ONE_GPU": "1"})
