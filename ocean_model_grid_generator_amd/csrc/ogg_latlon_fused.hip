@@ -28,20 +28,7 @@ __global__ __launch_bounds__(256) void latlon_tables_kernel(RowsParams p) {
     if (k < n_rows) {
         int bi = 0;
         while (bi + 1 < f.n_bands && k >= p.row0[bi + 1]) ++bi;
-        const ogg_latlon_band& b = f.band[bi];
-        const long j = k - p.row0[bi];
-        const long n_cell_rows = f.metrics ? b.n_cell_rows : 0;
-        RowScalars r = {0.0, 0.0, 0.0, 0.0};
-        if (j < b.n_pt_rows || j - 1 < n_cell_rows) {      // the same rows latlon_fused_body gives scalars to
-            r.lat = axis_lat(b, b.k0 + j, f.Ni);
-            const double lv = (0.5 * (r.lat + r.lat)) * kPi180;
-            sincos(lv, &r.sl, &r.cl);
-            if (j < n_cell_rows) {                          // dy of cell row j needs lat_{j+1}
-                const double dyj = (axis_lat(b, b.k0 + j + 1, f.Ni) - r.lat) * kPi180;
-                r.dy = f.Re * sqrt(dyj * dyj + 0.0);
-            }
-        }
-        const_cast<RowScalars*>(p.row_tab)[k] = r;
+        const_cast<RowScalars*>(p.row_tab)[k] = latlon_row_scalars(f, f.band[bi], k - p.row0[bi]);
     } else if (k < n_rows + f.ni1) {
         const long i = k - n_rows;
         const ColScalars c = column_scalars(f, i);

@@ -29,6 +29,10 @@ constexpr int LF_TX = 256;
 constexpr int LF_ROWS = 32;  // maximum rows per strip (LDS row table); small bands use fewer (>= 8) so that there are enough strips
 constexpr int LF_MAX_BANDS = 4;
 
+struct RowScalars {
+    double lat, sl, cl, dy;
+};
+
 struct FusedParams {
     int n_bands;
     ogg_latlon_band band[LF_MAX_BANDS];
@@ -38,10 +42,10 @@ struct FusedParams {
     int rows_per_block;
     double Re, Re2;
     int metrics;
-};
-
-struct RowScalars {
-    double lat, sl, cl, dy;
+    // the per-row scalars of every band as a table in device memory (NULL: the strips compute their rows' scalars themselves):
+    // band k's rows 0 .. n_pt_rows at row0[k] (latlon_row_table_body fills it; latlon_fused_body<NT, true> reads it)
+    const RowScalars* row_tab;
+    long row0[LF_MAX_BANDS + 1];
 };
 
 // latitude of axis index k (OGG:336 / OGG:835 / explicit)
@@ -53,6 +57,37 @@ OGG_DEV double axis_lat(const ogg_latlon_band& b, long k, double Ni) {
     }
     return b.lat1d[k];
 }
+
+// The scalars of row j of band b: latitude, sin / cos of it, and dy of cell row j (which needs lat_{j+1}) -- the operations the strips
+// perform when they have no table (latlon_fused_body<NT, false>), on the same operands: the same bits.  Rows that nothing reads are zero.
+OGG_DEV RowScalars latlon_row_scalars(const FusedParams& f, const ogg_latlon_band& b, long j) {
+    const long n_cell_rows = f.metrics ? b.n_cell_rows : 0;
+    RowScalars r = {0.0, 0.0, 0.0, 0.0};
+    if (j < b.n_pt_rows || j - 1 < n_cell_rows) {      // the same rows latlon_fused_body gives scalars to
+        r.lat = axis_lat(b, b.k0 + j, f.Ni);
+        const double lv = (0.5 * (r.lat + r.lat)) * kPi180;
+        sincos(lv, &r.sl, &r.cl);
+        if (j < n_cell_rows) {                          // dy of cell row j needs lat_{j+1}
+            const double dyj = (axis_lat(b, b.k0 + j + 1, f.Ni) - r.lat) * kPi180;
+            r.dy = f.Re * sqrt(dyj * dyj + 0.0);
+        }
+    }
+    return r;
+}
+
+// workgroup b of n_wg: the row table of all bands (f.row_tab), one thread per row.  A role of the fused pass's table launch (ogg_pass.hip):
+// atan(sinh) and sincos want 80 VGPRs more than the strips' row loop, and a strip role without them lets launch B run at twice the
+// occupancy.
+OGG_DEV void latlon_row_table_body(const FusedParams& f, long b, long n_wg) {
+    const long n_rows = f.row0[f.n_bands];
+    RowScalars* tab = const_cast<RowScalars*>(f.row_tab);
+    for (long k = b * LF_TX + threadIdx.x; k < n_rows; k += n_wg * LF_TX) {
+        int bi = 0;
+        while (bi + 1 < f.n_bands && k >= f.row0[bi + 1]) ++bi;
+        tab[k] = latlon_row_scalars(f, f.band[bi], k - f.row0[bi]);
+    }
+}
+inline long latlon_row_table_blocks(const FusedParams& f) { return f.n_bands ? (f.row0[f.n_bands] + LF_TX - 1) / LF_TX : 0; }
 
 // column-only quantities (OGG:696, 713, 725-727) of column i
 struct ColScalars {
@@ -183,7 +218,9 @@ inline long latlon_gx(long ni1) { return (ni1 + LF_COLS - 1) / LF_COLS; }
 // the claims run out.  Helpers sit at the END of a fused launch, so they start when the compute workgroups drain: if the strips are
 // what is left by then (1/16 degree on a box with a slow write path: 300 us of a 1.2 ms launch with nothing but the 90 resident
 // workgroups running) the whole chip finishes them; if not, they find nothing to claim and leave.  s_claim: one LDS word.
-template <bool NT>
+// TAB: the per-row scalars come from p.row_tab (built by an EARLIER launch, or by the previous pass's launch B: the stream's order is the
+// dependence) instead of being evaluated here.
+template <bool NT, bool TAB = false>
 OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, long gx, long gy, long strip_lo, long strip_hi,
                                unsigned* claims = nullptr, bool helper = false, int* s_claim = nullptr, bool pool = false) {
     const long v = xcd_contiguous(b, gx * gy);   // virtual index: the workgroups of XCD x are consecutive
@@ -242,23 +279,27 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
         const long je = (js + p.rows_per_block < b.n_pt_rows) ? js + p.rows_per_block : b.n_pt_rows;
         const int nrows = (int)(je - js);
         // per-row scalars for rows js .. je (row je only when a cell row needs it)
-        if (tid <= nrows) {
-            const long j = js + tid;
-            const bool have = (tid < nrows) || (j - 1 < n_cell_rows);
-            RowScalars r = {0.0, 0.0, 0.0, 0.0};
-            if (have) {
-                r.lat = axis_lat(b, b.k0 + j, p.Ni);
-                const double lv = (0.5 * (r.lat + r.lat)) * kPi180;
-                sincos(lv, &r.sl, &r.cl);
+        if (TAB) {
+            if (tid <= nrows) s_row[tid] = p.row_tab[p.row0[bi] + js + tid];
+        } else {
+            if (tid <= nrows) {
+                const long j = js + tid;
+                const bool have = (tid < nrows) || (j - 1 < n_cell_rows);
+                RowScalars r = {0.0, 0.0, 0.0, 0.0};
+                if (have) {
+                    r.lat = axis_lat(b, b.k0 + j, p.Ni);
+                    const double lv = (0.5 * (r.lat + r.lat)) * kPi180;
+                    sincos(lv, &r.sl, &r.cl);
+                }
+                s_row[tid] = r;
             }
-            s_row[tid] = r;
-        }
-        __syncthreads();
-        if (p.metrics && tid < nrows) {  // dy of cell row j needs lat_{j+1}
-            const long j = js + tid;
-            if (j < n_cell_rows) {
-                const double dyj = (s_row[tid + 1].lat - s_row[tid].lat) * kPi180;
-                s_row[tid].dy = p.Re * sqrt(dyj * dyj + 0.0);
+            __syncthreads();
+            if (p.metrics && tid < nrows) {  // dy of cell row j needs lat_{j+1}
+                const long j = js + tid;
+                if (j < n_cell_rows) {
+                    const double dyj = (s_row[tid + 1].lat - s_row[tid].lat) * kPi180;
+                    s_row[tid].dy = p.Re * sqrt(dyj * dyj + 0.0);
+                }
             }
         }
         __syncthreads();
@@ -305,8 +346,11 @@ inline int plan_latlon(int n_bands, const ogg_latlon_band* bands, long ni1, doub
     long rpb = (total_rows * gx + 2047) / 2048;  // aim at >= 2048 row strips x column tiles
     rpb = rpb < 8 ? 8 : (rpb > LF_ROWS ? LF_ROWS : rpb);   // >= 8 rows per strip: the per-strip set-up (row scalars, two barriers) is worth ~2 rows
     if (const char* e = getenv("OGG_LL_ROWS_PER_STRIP")) rpb = atol(e) < 1 ? 1 : (atol(e) > LF_ROWS ? LF_ROWS : atol(e));   // (experiments)
-    p.strip0[0] = 0;
-    for (int k = 0; k < p.n_bands; ++k) p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
+    p.strip0[0] = 0, p.row0[0] = 0;
+    for (int k = 0; k < p.n_bands; ++k) {
+        p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
+        p.row0[k + 1] = p.row0[k] + p.band[k].n_pt_rows + 1;   // rows 0 .. n_pt_rows: the last cell row reads lat and sin of the row above it
+    }
     p.ni1 = ni1, p.lon0 = lon0, p.lenlon = lenlon, p.Ni = (double)(ni1 - 1);
     p.rows_per_block = (int)rpb, p.Re = Re, p.Re2 = pow(Re, 2.0), p.metrics = metrics;
     return OGG_OK;

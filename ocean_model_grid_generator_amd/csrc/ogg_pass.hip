@@ -75,6 +75,7 @@ struct PassAParams {
     int dq_order;
     DpMeshParams dm;        // ... and the reset of the look-back words of its mesh
     long n_dm_reset;
+    long n_ll_tab;          // workgroups of the lat-lon row table (ll.row_tab; 0: the strips of launch B evaluate their rows themselves)
 };
 
 // the roles of launch A that write nothing but the cap workspaces (tables, cleared words and counters)
@@ -93,7 +94,12 @@ OGG_DEV void pass_table_roles(const PassAParams& a, long b) {
         return;
     }
     b -= a.n_dq_tab;
-    if (b < a.n_dm_reset) dpole_mesh_reset_body(a.dm, b, a.n_dm_reset);
+    if (b < a.n_dm_reset) {
+        dpole_mesh_reset_body(a.dm, b, a.n_dm_reset);
+        return;
+    }
+    b -= a.n_dm_reset;
+    if (b < a.n_ll_tab) latlon_row_table_body(a.ll, b, a.n_ll_tab);
 }
 
 template <int N>
@@ -126,6 +132,11 @@ __global__ __launch_bounds__(PASS_TX) void pass_a_kernel(PassAParams a) {
         return;
     }
     b -= a.n_dm_reset;
+    if (b < a.n_ll_tab) {
+        latlon_row_table_body(a.ll, b, a.n_ll_tab);
+        return;
+    }
+    b -= a.n_ll_tab;
     if (b < a.n_mesh) bipolar_mesh_body<false>(a.mesh, lds.mesh, b % a.mesh_gx, b / a.mesh_gx);
 }
 
@@ -192,8 +203,12 @@ extern "C" int ogg_timeline_strips(unsigned long long* out512) {
 #define OGG_TL_DONE(r)
 #endif
 
-template <int N>
-__global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
+// TAB: the lat-lon strips read their rows' scalars from the table the table launch built (a.ll.row_tab).  Without atan(sinh) and sincos in
+// it the strip role needs 81 VGPRs instead of 176, the kernel what its cap roles need (<= 128: four waves per SIMD instead of two), and
+// the latency-bound cap workgroups of the launch get twice the wave slots.  TAB = false is the launch of a pass that owns no memory to
+// keep a table in (the one-shot entry points, a one-slot plan).
+template <int N, bool TAB>
+__global__ __launch_bounds__(PASS_TX, TAB ? 4 : 1) void pass_b_kernel(PassBParams a) {
     __shared__ PassLds lds;
     __shared__ unsigned s_slot;
     __shared__ int s_claim;
@@ -216,9 +231,9 @@ __global__ __launch_bounds__(PASS_TX) void pass_b_kernel(PassBParams a) {
             b = r % n;
         }
         if (a.share.nt)
-            latlon_fused_body<true>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim, a.share.pool != 0);
+            latlon_fused_body<true, TAB>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim, a.share.pool != 0);
         else
-            latlon_fused_body<false>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim, a.share.pool != 0);
+            latlon_fused_body<false, TAB>(a.ll, lds.ll, b, a.share.gx, a.share.gy, a.share.strip_lo, a.share.strip_hi, a.share.claims, helper, &s_claim, a.share.pool != 0);
         OGG_TL_DONE(helper ? 1 : 0);
         return;
     }
@@ -424,7 +439,11 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         P.alg_bytes[3] = dq_literal ? dpole_quad_bytes(*scap) : 0.0;
     }
     A.share = make_share(ll, 0, s1, ni1, !have_cap && !have_dp);
-    P.na = (unsigned)(A.share.n_wg + A.n_tab + A.n_dq_tab + A.n_dm_reset + A.n_mesh);
+    // the strips of launch B read their rows' scalars from ll.row_tab when the caller has memory for it (a two-slot plan handle); the
+    // strips of launch A (a pass without launch B) always evaluate them themselves: nothing orders a table before them
+    if (!(launch_b && ll.row_tab && n_strips_ll > 0)) A.ll.row_tab = nullptr, B.ll.row_tab = nullptr;
+    A.n_ll_tab = B.ll.row_tab ? latlon_row_table_blocks(ll) : 0;
+    P.na = (unsigned)(A.share.n_wg + A.n_tab + A.n_dq_tab + A.n_dm_reset + A.n_ll_tab + A.n_mesh);
     if (launch_b) {
         // dispatch order of the compute roles.  A big launch (>= ~2 M quadrature cells: a whole 1/8 degree cap or half of it) puts the
         // quadrature strips first (long, issue-bound waves) and the meshes last -- their short workgroups fill the slots the draining
@@ -485,13 +504,12 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
     }
     if (int e = mark(1)) return e;
     if (P.launch_b) {
-        if (next && n_next > 0) {
-            PassBParams b = P.B;
-            b.next = next, b.n_next = n_next;
-            pass_b_kernel<N><<<P.nb + (unsigned)n_next, PASS_TX, 0, st>>>(b);
-        } else {
-            pass_b_kernel<N><<<P.nb, PASS_TX, 0, st>>>(P.B);
-        }
+        PassBParams b = P.B;
+        if (next && n_next > 0) b.next = next, b.n_next = n_next;
+        if (b.ll.row_tab)
+            pass_b_kernel<N, true><<<P.nb + (unsigned)b.n_next, PASS_TX, 0, st>>>(b);
+        else
+            pass_b_kernel<N, false><<<P.nb + (unsigned)b.n_next, PASS_TX, 0, st>>>(b);
         OGG_LAUNCH_CHECK();
     }
     if (int e = mark(2)) return e;
@@ -510,10 +528,11 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
 }
 
 int build_pass_plan_any(int n_latlon, const ogg_latlon_band* latlon, long ni1, double lon0, double lenlon, double Re, int metrics,
-                        const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, PassPlan& P) {
+                        const ogg_bipolar_band* cap, const ogg_dpole_band* south_cap, PassPlan& P, const RowScalars* row_tab = nullptr) {
     FusedParams ll;
     long points = 0;
     if (int e = plan_latlon(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, ll, points)) return e;
+    ll.row_tab = row_tab;   // (memory for ll.row0[n_bands] entries, or NULL)
     int order = 5;
     if (cap && cap->n_pt_rows > 0) {
         OGG_REQUIRE(cap->Ni + 1 == ni1, OGG_ESHAPE, "ogg_tripolar_pass: cap has %ld columns, the lat-lon bands %ld", cap->Ni + 1, ni1);
@@ -579,6 +598,7 @@ struct PassPipe {
     void* own_ws[2][2] = {};                // [slot][bipolar cap, southern cap]: with two slots BOTH are the plan's own allocations -- what is in
                                             // them outlives a run (the tables of the next pass), so nobody else may write there; the caller's
                                             // workspaces are used by a one-slot plan only
+    void* own_row_tab[2] = {};              // [slot]: the lat-lon row table of the slot's passes (RowScalars per row; OGG_PASS_LL_TABLE=0: none)
     PassAParams* dev_a = nullptr;           // [2]
     unsigned long long runs = 0;            // passes issued
     int ready_slot = -1;                    // the slot whose tables the previous pass's launch B built
@@ -604,6 +624,8 @@ struct PassPipe {
             for (auto& slot_ws : own_ws)
                 for (void* w : slot_ws)
                     if (w) (void)hipFree(w);
+            for (void* w : own_row_tab)
+                if (w) (void)hipFree(w);
             if (dev_a) (void)hipFree(dev_a);
             (void)hipSetDevice(current);
         }
@@ -624,7 +646,13 @@ int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, doubl
     OGG_HIP_CHECK(hipGetDevice(&H.device));
     const bool have_cap = cap && cap->n_pt_rows > 0 && cap->workspace, have_dp = south_cap && south_cap->n_pt_rows > 0;
     H.n_slots = 2;   // from here on ~PassPipe frees what has been allocated
+    const long n_tab_rows = H.slot[0].A.ll.n_bands ? H.slot[0].A.ll.row0[H.slot[0].A.ll.n_bands] : 0;
+    const bool row_table = n_tab_rows > 0 && env_long("OGG_PASS_LL_TABLE", 1) != 0;
     for (int k = 0; k < 2; ++k) {
+        if (row_table) {
+            OGG_HIP_CHECK(hipMalloc(&H.own_row_tab[k], (size_t)n_tab_rows * sizeof(RowScalars)));
+            OGG_HIP_CHECK(hipMemset(H.own_row_tab[k], 0, (size_t)n_tab_rows * sizeof(RowScalars)));
+        }
         ogg_bipolar_band c{};
         ogg_dpole_band d{};
         if (have_cap) {
@@ -640,7 +668,7 @@ int build_pass_pipe(int n_latlon, const ogg_latlon_band* latlon, long ni1, doubl
             d.workspace = H.own_ws[k][1];
         }
         if (int e = build_pass_plan_any(n_latlon, latlon, ni1, lon0, lenlon, Re, metrics, cap ? (have_cap ? &c : cap) : nullptr,
-                                        south_cap ? (have_dp ? &d : south_cap) : nullptr, H.slot[k]))
+                                        south_cap ? (have_dp ? &d : south_cap) : nullptr, H.slot[k], static_cast<const RowScalars*>(H.own_row_tab[k])))
             return e;
     }
     for (PassPlan& P : H.slot) route_top_row_through_workspace(P);

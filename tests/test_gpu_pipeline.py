@@ -335,12 +335,14 @@ def test_function_level_calls_between_two_passes_of_a_plan(sg, name):
 @pytest.mark.parametrize("name,dp_arc", [("r0.5_dp", "literal"), ("r0.5_dp", "chord"), ("r1_cut2", "literal"), ("r0.25_even", "literal")])
 def test_pass_does_not_depend_on_tiling_knobs(sg, name, dp_arc, monkeypatch):
     """Chunk lengths of both quadratures (one row ... the whole cap), rows per workgroup of both meshes, the number of resident lat-lon
-    workgroups and of their helpers, strips handed out from per-tile counters or owned, the dispatch order of the roles, the weights of the band split (read when the PLAN is built): none of
-    them may change a bit of the result."""
+    workgroups and of their helpers, strips handed out from per-tile counters or owned, the strips' row scalars read from the table the table
+    launch builds (the default of a plan handle) or evaluated by the strips themselves (OGG_PASS_LL_TABLE=0), the dispatch order of the
+    roles, the weights of the band split (read when the PLAN is built): none of them may change a bit of the result."""
     plan = sg.SupergridPlan(dp_arc=dp_arc, **CONFIGS[name])
     base = run_pass_mode(sg, plan, 1)
     knobs = ({"OGG_QUAD_TARGET_WAVES": "1", "OGG_DPQUAD_TARGET_WAVES": "1", "OGG_MESH_ROWS": "32", "OGG_DPMESH_ROWS": "1",
-              "OGG_PASS_LL_WG": "7", "OGG_PASS_LL_WG_MID": "7", "OGG_PASS_LL_WG_SMALL": "7", "OGG_PASS_ORDER": "43210", "OGG_PASS_LL_NT": "0", "OGG_PASS_LL_HELPERS": "0", "OGG_PASS_LL_POOL": "1", "OGG_LL_ROWS_PER_STRIP": "5"},
+              "OGG_PASS_LL_WG": "7", "OGG_PASS_LL_WG_MID": "7", "OGG_PASS_LL_WG_SMALL": "7", "OGG_PASS_ORDER": "43210", "OGG_PASS_LL_NT": "0", "OGG_PASS_LL_HELPERS": "0", "OGG_PASS_LL_POOL": "1", "OGG_LL_ROWS_PER_STRIP": "5",
+              "OGG_PASS_LL_TABLE": "0"},
              {"OGG_QUAD_TARGET_WAVES": "1000000", "OGG_DPQUAD_TARGET_WAVES": "1000000", "OGG_MESH_ROWS": "1", "OGG_DPMESH_ROWS": "3",
               "OGG_PASS_LL_WG": "1000", "OGG_PASS_LL_WG_MID": "1000", "OGG_PASS_LL_WG_SMALL": "1000", "OGG_PASS_ORDER": "01234",
               "OGG_PASS_LL_HELPERS": "5", "OGG_BP_ROW_COST": "2,1.5,3", "OGG_TOP_RANK_TAIL_US": "20"},
