@@ -307,7 +307,8 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // (184: +1.5 %, 138: +1 %), half / quarter of the 1/8 degree grid 150-180, an eighth 120 as before
     // pooled strips (round 5, after the mirrored caps): every XCD takes what it can write, the strips end together, and FEWER resident
     // workgroups are best -- the cap workgroups get the wave slots, the strips still end with them: 1/8 degree 84-96 (0.2171 -> 0.2005 ms
-    // on a fast box, 0.2397 -> 0.2158 on a slow one; 156: 0.2137), 1/16 degree 72-138 (-2 ... -3 %); with a displaced-pole quadrature in
+    // on a fast box, 0.2397 -> 0.2158 on a slow one; 156: 0.2137), 1/16 degree 72-138 (-2 ... -3 %; 72 against 96: -1.2 % on three boxes
+    // with the row table); with a displaced-pole quadrature in
     // the launch 48-60 and as many helpers behind the compute roles (0.3145 -> 0.286)
     if (pool < 0) pool = (int)env_long("OGG_PASS_LL_POOL", (light || points >= 16000000) ? 1 : 0);
     s.pool = pool;
@@ -315,7 +316,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // (0.1012 -> 0.0962 ms), a quarter 96 (0.0572 -> 0.0561; the last rank of four 0.0663 -> 0.0597), an eighth 120 (0.0307 -> 0.0295);
     // the 1/4 degree grid with its displaced-pole quadrature is better off with owned blocks (+1 ... +9 % pooled)
     long max_wg = alone ? 2048
-                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? 96 : 60) : (light ? 156 : 90))
+                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? (points >= 48000000 ? 72 : 96) : 60) : (light ? 156 : 90))
                                               : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", pool ? 96 : (light ? 150 : 90))
                                                                    : env_long("OGG_PASS_LL_WG_SMALL", points >= 4000000 ? (pool ? 96 : (light ? 180 : 120)) : 120)));
     long gy = hi - lo;
@@ -361,6 +362,7 @@ struct PassPlan {
     int dq_order;
     bool have_quad, dq_literal, launch_b;
     unsigned na, nb, nd;
+    unsigned b_lds_pad;        // dynamic LDS bytes launch B asks for on top of its static 12 KB: nothing uses them, they cap the workgroups per CU
     double alg_bytes[4];
 };
 
@@ -471,7 +473,9 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         const long helpers = env_long("OGG_PASS_LL_HELPERS", (B.share.points >= 16000000 && !light) ? 2 : 0);
         if (B.share.pool && B.share.n_wg > 0 && B.share.gx <= QUAD_LL_CLAIM_WORDS) {
             B.share.claims = qp.p.ll_claims;
-            B.share.n_help = B.share.n_wg * env_long("OGG_PASS_LL_POOL_HELPERS", light ? 0 : 1);
+            // (with the row table -- launch B at four waves per SIMD -- the compute roles no longer leave a tail for helpers to fill:
+            // config 4 0.2776 -> 0.2710 ms without them, same process)
+            B.share.n_help = B.share.n_wg * env_long("OGG_PASS_LL_POOL_HELPERS", (light || B.ll.row_tab) ? 0 : 1);
         } else if (B.share.pool) {
             B.share.pool = 0;
         } else if (have_quad && helpers > 0 && B.share.n_wg > 0 && 2 * B.share.n_wg <= QUAD_LL_CLAIM_WORDS) {
@@ -479,6 +483,11 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
             B.share.n_help = B.share.n_wg * helpers;
         }
         P.nb = (unsigned)(B.share.n_wg + B.n_mesh + B.n_dmesh + B.n_guard + B.n_fast + B.n_dquad + B.share.n_help);
+        // Launch B with the row table runs four workgroups per CU.  A whole-grid launch with mirrored caps is bound by its writes, and there
+        // three per CU are 0.5-1.5 % faster (fewer cap workgroups writing at once: 1/8 degree 0.2359 -> 0.2343 ms, same process; the same
+        // from a build held to three by its registers); the launches that carry a displaced-pole quadrature or a share of the grid want the
+        // four (1/4 degree OM4 0.0650 against 0.0685).  41000 bytes of unused dynamic LDS on top of the static 12 KB: three fit in 160 KB.
+        P.b_lds_pad = (unsigned)env_long("OGG_PASS_B_LDS_PAD", (B.ll.row_tab && light && B.share.points >= 16000000) ? 41000 : 0);
     }
     P.nd = dq_literal ? (unsigned)(dq.gx * dq.n_chunks) : 0u;
     P.have_quad = have_quad, P.dq_literal = dq_literal, P.launch_b = launch_b;
@@ -507,7 +516,7 @@ int run_pass_plan(const PassPlan& P, hipEvent_t* ev, double* alg_bytes4, hipStre
         PassBParams b = P.B;
         if (next && n_next > 0) b.next = next, b.n_next = n_next;
         if (b.ll.row_tab)
-            pass_b_kernel<N, true><<<P.nb + (unsigned)b.n_next, PASS_TX, 0, st>>>(b);
+            pass_b_kernel<N, true><<<P.nb + (unsigned)b.n_next, PASS_TX, P.b_lds_pad, st>>>(b);
         else
             pass_b_kernel<N, false><<<P.nb + (unsigned)b.n_next, PASS_TX, 0, st>>>(b);
         OGG_LAUNCH_CHECK();

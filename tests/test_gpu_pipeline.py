@@ -337,7 +337,8 @@ def test_pass_does_not_depend_on_tiling_knobs(sg, name, dp_arc, monkeypatch):
     """Chunk lengths of both quadratures (one row ... the whole cap), rows per workgroup of both meshes, the number of resident lat-lon
     workgroups and of their helpers, strips handed out from per-tile counters or owned, the strips' row scalars read from the table the table
     launch builds (the default of a plan handle) or evaluated by the strips themselves (OGG_PASS_LL_TABLE=0), the dispatch order of the
-    roles, the weights of the band split (read when the PLAN is built): none of them may change a bit of the result."""
+    roles, the unused dynamic LDS that caps launch B's workgroups per CU, the weights of the band split (read when the PLAN is built): none
+    of them may change a bit of the result."""
     plan = sg.SupergridPlan(dp_arc=dp_arc, **CONFIGS[name])
     base = run_pass_mode(sg, plan, 1)
     knobs = ({"OGG_QUAD_TARGET_WAVES": "1", "OGG_DPQUAD_TARGET_WAVES": "1", "OGG_MESH_ROWS": "32", "OGG_DPMESH_ROWS": "1",
@@ -345,7 +346,7 @@ def test_pass_does_not_depend_on_tiling_knobs(sg, name, dp_arc, monkeypatch):
               "OGG_PASS_LL_TABLE": "0"},
              {"OGG_QUAD_TARGET_WAVES": "1000000", "OGG_DPQUAD_TARGET_WAVES": "1000000", "OGG_MESH_ROWS": "1", "OGG_DPMESH_ROWS": "3",
               "OGG_PASS_LL_WG": "1000", "OGG_PASS_LL_WG_MID": "1000", "OGG_PASS_LL_WG_SMALL": "1000", "OGG_PASS_ORDER": "01234",
-              "OGG_PASS_LL_HELPERS": "5", "OGG_BP_ROW_COST": "2,1.5,3", "OGG_TOP_RANK_TAIL_US": "20"},
+              "OGG_PASS_LL_HELPERS": "5", "OGG_BP_ROW_COST": "2,1.5,3", "OGG_TOP_RANK_TAIL_US": "20", "OGG_PASS_B_LDS_PAD": "41000"},
              {"OGG_QUAD_TARGET_WAVES": "300", "OGG_DPQUAD_TARGET_WAVES": "200", "OGG_MESH_ROWS": "5", "OGG_DPMESH_ROWS": "5",
               "OGG_PASS_LL_POOL": "1", "OGG_PASS_LL_POOL_HELPERS": "2", "OGG_PASS_LL_WG_SMALL": "40", "OGG_LL_ROWS_PER_STRIP": "32"})
     for world, kn in zip((1, 3, 2), knobs):
