@@ -309,7 +309,8 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
             latlon_rows<false, NT>(p, b, s_row, js, nrows, n_cell_rows, i0, c0, c1);
         if (pool && tid == 0) {
             // this wave has issued at least three stores per row since it asked (x, y, angle_dx of its first column)
-            const unsigned t = nrows >= 6 ? ticket_answer<16>(asked) : ticket_answer<0>(asked);
+            const unsigned t = nrows >= 6 ? ticket_answer<16>(asked) : nrows == 5 ? ticket_answer<12>(asked) : nrows == 4 ? ticket_answer<8>(asked)
+                               : nrows == 3 ? ticket_answer<6>(asked) : ticket_answer<0>(asked);
             *s_claim = t < n_pool ? (int)t : -1;
         }
         __syncthreads();  // the row table is rewritten by the next strip
@@ -319,6 +320,14 @@ OGG_DEV void latlon_fused_body(const FusedParams& p, RowScalars* s_row, long b, 
 __global__ __launch_bounds__(LF_TX) void latlon_fused_kernel(FusedParams p) {
     __shared__ RowScalars s_row[LF_ROWS + 1];
     latlon_fused_body<false>(p, s_row, (long)blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, 0, p.strip0[p.n_bands]);
+}
+
+// the row strips of the bands at `rpb` rows per strip (1 .. LF_ROWS)
+inline void set_rows_per_strip(FusedParams& p, long rpb) {
+    rpb = rpb < 1 ? 1 : (rpb > LF_ROWS ? LF_ROWS : rpb);
+    p.rows_per_block = (int)rpb;
+    p.strip0[0] = 0;
+    for (int k = 0; k < p.n_bands; ++k) p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
 }
 
 // Validates the bands and fills the kernel parameters; returns the number of points (0: nothing to do).
@@ -346,13 +355,11 @@ inline int plan_latlon(int n_bands, const ogg_latlon_band* bands, long ni1, doub
     long rpb = (total_rows * gx + 2047) / 2048;  // aim at >= 2048 row strips x column tiles
     rpb = rpb < 8 ? 8 : (rpb > LF_ROWS ? LF_ROWS : rpb);   // >= 8 rows per strip: the per-strip set-up (row scalars, two barriers) is worth ~2 rows
     if (const char* e = getenv("OGG_LL_ROWS_PER_STRIP")) rpb = atol(e) < 1 ? 1 : (atol(e) > LF_ROWS ? LF_ROWS : atol(e));   // (experiments)
-    p.strip0[0] = 0, p.row0[0] = 0;
-    for (int k = 0; k < p.n_bands; ++k) {
-        p.strip0[k + 1] = p.strip0[k] + (p.band[k].n_pt_rows + rpb - 1) / rpb;
-        p.row0[k + 1] = p.row0[k] + p.band[k].n_pt_rows + 1;   // rows 0 .. n_pt_rows: the last cell row reads lat and sin of the row above it
-    }
+    p.row0[0] = 0;
+    for (int k = 0; k < p.n_bands; ++k) p.row0[k + 1] = p.row0[k] + p.band[k].n_pt_rows + 1;   // rows 0 .. n_pt_rows: the last cell row reads lat and sin of the row above it
     p.ni1 = ni1, p.lon0 = lon0, p.lenlon = lenlon, p.Ni = (double)(ni1 - 1);
-    p.rows_per_block = (int)rpb, p.Re = Re, p.Re2 = pow(Re, 2.0), p.metrics = metrics;
+    p.Re = Re, p.Re2 = pow(Re, 2.0), p.metrics = metrics;
+    set_rows_per_strip(p, rpb);
     return OGG_OK;
 }
 

@@ -464,6 +464,19 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         // the strips to hide behind: 1/8 degree with the displaced pole 0.257 ms at 90 resident workgroups, 0.269 at 120, 0.285 at 150)
         const bool light = have_cap && ogg::cap_symmetry(cap->symmetry) && B.n_dquad == 0;
         B.share = make_share(ll, s1, n_strips_ll, ni1, false, light, have_quad ? -1 : 0);
+        // Strips that are handed out from the tiles' counters AND copy their rows' scalars from the table cost next to nothing to start
+        // (one 32-byte load per row, one barrier; the ticket for the next strip is already on its way), and short ones keep the rows the
+        // resident workgroups write at any moment close together: 6 rows instead of the 21 / 32 that paid for a strip's own atan(sinh) and
+        // sincos -- 1/8 degree 0.2216 -> 0.2035 ms, 1/16 degree 1.1464 -> 1.0672, the upper half of the 1/8 degree grid 0.1075 -> 0.1039
+        // (8), an eighth +-0 (same process each; 4 rows: the ticket's answer no longer has 16 stores to hide behind).  Not next to a
+        // displaced-pole quadrature (60 resident workgroups: 21 rows 0.2696, 16 0.2724, 12 0.2764).
+        if (B.share.pool && B.ll.row_tab && light && !getenv("OGG_LL_ROWS_PER_STRIP")) {
+            const long rpb = env_long("OGG_PASS_LL_ROWS_TABLE", 6);
+            if (rpb > 0 && rpb != B.ll.rows_per_block) {
+                set_rows_per_strip(B.ll, rpb), set_rows_per_strip(A.ll, rpb);
+                B.share = make_share(B.ll, 0, B.ll.strip0[B.ll.n_bands], ni1, false, light, have_quad ? -1 : 0);
+            }
+        }
         // helper workgroups for the lat-lon strips at the end of the launch (ogg_latlon_fused_dev.h): the claim counters live in the
         // bipolar cap's workspace and are zeroed by launch A with its tables
         // (measured: 1/8 degree whole grid 0.246 -> 0.237 ms, 1/16 degree 1.23 -> 1.19; half, a quarter, an eighth of the 1/8 degree grid
