@@ -710,8 +710,12 @@ def main():
                 v.update({"ms": round(v["ms"], 5), "alg_bytes": int(v["alg_bytes"]), "alg_GBps": round(gbs, 1),
                           "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
             dom = max(launches, key=lambda k: launches[k]["ms"])
-            kname = {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5>", "pass_tail": "bipolar_quad_tail_kernel<5>",
+            # launch B of a plan handle reads the strips' row scalars from a table (pass_b_kernel<5, true>: 128 VGPRs, four waves per
+            # SIMD); the one-shot entry points and one-slot plans run pass_b_kernel<5, false>
+            kname = {"pass_a": "pass_a_kernel<5>", "pass_b": "pass_b_kernel<5, true>", "pass_tail": "bipolar_quad_tail_kernel<5>",
                      "pass_dpquad": "pass_d_kernel<4>"}[dom]
+            if dom == "pass_b" and kname not in valu:
+                kname = next((k for k in valu if k.startswith("pass_b_kernel<5")), kname)
             vc = valu.get(kname)
             roof = {"kernel": kname, "bound": "hbm", "achieved": launches[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": launches[dom]["hbm_frac"], "traffic": pmc.get(dom),
