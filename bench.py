@@ -638,22 +638,31 @@ def main():
             dp_other = {"error": repr(exc)}
     # what this box's write path gives a plain fill right now, in this process (after the timed region): the boxes of the pool differ by 20 %
     # in what they sustain and one box moves by as much within minutes, so a launch's GB/s is best read beside it
-    fill_ref = None
+    fill_ref = fill_ref_sized = None
     if rank == 0 and args.as_rank is None:
-        try:
-            buf = torch.empty(1 << 27, dtype=torch.float64, device=device)   # 1 GiB
-            for _ in range(5):
+        def time_fill(n_doubles, reps):
+            buf = torch.empty(n_doubles, dtype=torch.float64, device=device)
+            for _ in range(3):
                 buf.fill_(1.0)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-            for _ in range(20):
+            for _ in range(reps):
                 buf.fill_(1.0)
             ev1.record()
             torch.cuda.synchronize()
-            fill_ref = round(20 * buf.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+            rate = round(reps * n_doubles * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
             del buf
+            return rate
+        try:
+            fill_ref = time_fill(1 << 27, 20)   # 1 GiB
+            # ... and a fill of as many bytes as one pass of this workload writes (48 B per cell), repeated like the passes are: a 1 GiB
+            # buffer written over and over keeps a quarter of its lines in the 256 MB Infinity Cache between two fills, a 4.9 GB one
+            # (1/16 degree) next to nothing -- the pass of a large grid is best read beside a fill of its own size
+            n_pass = plan.cells * 6 // world
+            if n_pass > (3 << 26):
+                fill_ref_sized = time_fill(n_pass, 8)
         except Exception as exc:  # never lose the bench line over the reference
-            fill_ref = None
+            pass
     power = None
     if args.power_probe > 0 and world == 1 and args.latlon == "fused" and args.as_rank is None:
         try:
@@ -728,10 +737,14 @@ def main():
                             "quadrature workgroups (fp64 VALU; with mirrored cap columns a third of round 4's arithmetic): the launch is "
                             "bound by its writes (DESIGN.md 4.1) unless `limited_by` says otherwise.  `plain_fill_GBps`: a 1 GiB "
                             "torch fill_ timed in this process after the region -- what this box's write path gives ONE contiguous stream "
-                            "right now.  `kernels` lists the stand-alone kernels, one after the other." % n_sampled}
+                            "right now (`plain_fill_of_the_pass_size_GBps`: the same for a buffer of 48 B x cells, when that is more than "
+                            "1.5 GiB: a buffer that size leaves nothing in the 256 MB Infinity Cache between two fills).  `kernels` lists the stand-alone kernels, one after the other." % n_sampled}
             if fill_ref:
                 roof["plain_fill_GBps"] = fill_ref
                 roof["achieved_over_plain_fill"] = round(roof["achieved"] / fill_ref, 4)
+            if fill_ref_sized:
+                roof["plain_fill_of_the_pass_size_GBps"] = fill_ref_sized
+                roof["achieved_over_plain_fill_of_the_pass_size"] = round(roof["achieved"] / fill_ref_sized, 4)
             if vc:
                 # issue-time floor of the launch: every wave64 VALU instruction occupies its SIMD for >= 4 cycles (quarter-rate fp64
                 # rcp/rsq/sqrt: 16), 1024 SIMDs, at the clock the counter run held
