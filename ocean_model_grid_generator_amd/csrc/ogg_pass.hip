@@ -288,7 +288,7 @@ long env_long(const char* name, long dflt) {
 
 // pool: 0 = every resident workgroup its own block of strips, 1 = the strips of a column tile are handed out from one counter
 // (ogg_latlon_fused_dev.h), -1 = the default: pooled when the launch is `light` or carries >= 16 M lat-lon points (OGG_PASS_LL_POOL overrides)
-LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone, bool light = false, int pool = 0) {
+LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool alone, bool light = false, int pool = 0, bool table = false) {
     LatlonShare s{};
     s.gx = latlon_gx(ni1);
     s.strip_lo = lo, s.strip_hi = hi;
@@ -316,7 +316,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // (0.1012 -> 0.0962 ms), a quarter 96 (0.0572 -> 0.0561; the last rank of four 0.0663 -> 0.0597), an eighth 120 (0.0307 -> 0.0295);
     // the 1/4 degree grid with its displaced-pole quadrature is better off with owned blocks (+1 ... +9 % pooled)
     long max_wg = alone ? 2048
-                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? (points >= 48000000 ? 72 : 96) : 60) : (light ? 156 : 90))
+                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? (points >= 48000000 ? 72 : 96) : (table ? 96 : 60)) : (light ? 156 : 90))
                                               : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", pool ? 96 : (light ? 150 : 90))
                                                                    : env_long("OGG_PASS_LL_WG_SMALL", points >= 4000000 ? (pool ? 96 : (light ? 180 : 120)) : 120)));
     long gy = hi - lo;
@@ -468,13 +468,14 @@ int build_pass_plan(const FusedParams& ll, long ni1, int metrics, const ogg_bipo
         // (one 32-byte load per row, one barrier; the ticket for the next strip is already on its way), and short ones keep the rows the
         // resident workgroups write at any moment close together: 6 rows instead of the 21 / 32 that paid for a strip's own atan(sinh) and
         // sincos -- 1/8 degree 0.2216 -> 0.2035 ms, 1/16 degree 1.1464 -> 1.0672, the upper half of the 1/8 degree grid 0.1075 -> 0.1039
-        // (8), an eighth +-0 (same process each; 4 rows: the ticket's answer no longer has 16 stores to hide behind).  Not next to a
-        // displaced-pole quadrature (60 resident workgroups: 21 rows 0.2696, 16 0.2724, 12 0.2764).
-        if (B.share.pool && B.ll.row_tab && light && !getenv("OGG_LL_ROWS_PER_STRIP")) {
+        // (8), an eighth +-0 (same process each; 4 rows: the ticket's answer no longer has 16 stores to hide behind).  Next to a
+        // displaced-pole quadrature short strips lose with its 60 resident strip workgroups (21 rows 0.2696, 12 0.2764, 6 0.2951) and win
+        // with 96 of them (0.2618 -> 0.2545, same process; 80: 0.2574, 120: 0.2644): the two go together.
+        if (B.share.pool && B.ll.row_tab && !getenv("OGG_LL_ROWS_PER_STRIP")) {
             const long rpb = env_long("OGG_PASS_LL_ROWS_TABLE", 6);
             if (rpb > 0 && rpb != B.ll.rows_per_block) {
                 set_rows_per_strip(B.ll, rpb), set_rows_per_strip(A.ll, rpb);
-                B.share = make_share(B.ll, 0, B.ll.strip0[B.ll.n_bands], ni1, false, light, have_quad ? -1 : 0);
+                B.share = make_share(B.ll, 0, B.ll.strip0[B.ll.n_bands], ni1, false, light, have_quad ? -1 : 0, true);
             }
         }
         // helper workgroups for the lat-lon strips at the end of the launch (ogg_latlon_fused_dev.h): the claim counters live in the
