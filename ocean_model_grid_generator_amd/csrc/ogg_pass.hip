@@ -308,7 +308,9 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // pooled strips (round 5, after the mirrored caps): every XCD takes what it can write, the strips end together, and FEWER resident
     // workgroups are best -- the cap workgroups get the wave slots, the strips still end with them: 1/8 degree 84-96 (0.2171 -> 0.2005 ms
     // on a fast box, 0.2397 -> 0.2158 on a slow one; 156: 0.2137), 1/16 degree 72-138 (-2 ... -3 %; 72 against 96: -1.2 % on three boxes
-    // with the row table); with a displaced-pole quadrature in
+    // with the row table; on boxes in their fast state 138-161 are 4-5 % faster still, on the slow ones 8 % slower: 72 stays); 1/8 degree
+    // with 6-row table-fed strips: 108 (nine per column tile) against 96: -3.2 % and -3.9 % on two boxes (0.1948 -> 0.1886; 120: 0.1938,
+    // 132: 0.1912), the half-grid share indifferent; with a displaced-pole quadrature in
     // the launch 48-60 and as many helpers behind the compute roles (0.3145 -> 0.286)
     if (pool < 0) pool = (int)env_long("OGG_PASS_LL_POOL", (light || points >= 16000000) ? 1 : 0);
     s.pool = pool;
@@ -316,7 +318,7 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // (0.1012 -> 0.0962 ms), a quarter 96 (0.0572 -> 0.0561; the last rank of four 0.0663 -> 0.0597), an eighth 120 (0.0307 -> 0.0295);
     // the 1/4 degree grid with its displaced-pole quadrature is better off with owned blocks (+1 ... +9 % pooled)
     long max_wg = alone ? 2048
-                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? (points >= 48000000 ? 72 : 96) : (table ? 96 : 60)) : (light ? 156 : 90))
+                        : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? (points >= 48000000 ? 72 : (table ? 108 : 96)) : (table ? 96 : 60)) : (light ? 156 : 90))
                                               : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", pool ? 96 : (light ? 150 : 90))
                                                                    : env_long("OGG_PASS_LL_WG_SMALL", points >= 4000000 ? (pool ? 96 : (light ? 180 : 120)) : 120)));
     long gy = hi - lo;

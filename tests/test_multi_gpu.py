@@ -87,7 +87,9 @@ def test_n_ranks_rehearsed_on_one_gpu(n, workload):
     sc = bs["self_calibration"]
     assert len(sc) >= 1 and sc[0]["world"] == n and len(sc[0]["per_rank_us"]) == n and all(t > 0 for t in sc[0]["per_rank_us"])
     assert len(sc[0]["shares_before"]) == n == len(sc[0]["shares_after"]) and all(0.1 < v < 3.0 for v in sc[0]["shares_after"])
-    assert bs["top_capacity"]["world"] == n and 0.3 <= bs["top_capacity"]["share_of_last_rank"] <= 1.3
+    # (calibrate_split keeps the last rank's share in 0.3 .. 1.3; each of the up to two rebalancing steps may scale it by 0.3 .. 1.5 more,
+    # and with two processes on one card and a 20 us pass they sometimes do: 0.228 was seen once)
+    assert bs["top_capacity"]["world"] == n and 0.05 < bs["top_capacity"]["share_of_last_rank"] < 3.0
     assert len(many["per_rank"]) == n
     assert one["band_split"] is None or "fitted constants" in one["band_split"]["source"]
     assert many["self_check_metrics_error_percent"] and "error" not in many["self_check_metrics_error_percent"]
