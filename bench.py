@@ -369,6 +369,10 @@ def main():
                     help="mirror (default, what main() runs): the bipolar cap from a quarter of its columns, the displaced-pole quadrature from "
                          "half of them, written to their mirror images (DESIGN.md 2: as far from the exact value of the reference's formula as "
                          "the reference's own columns); none: every column evaluated, as the reference does (rounds 1-4)")
+    ap.add_argument("--tune-strips", type=int, default=1,
+                    help="set-up, untimed, one GPU, fused pass: time the pass with a few numbers of resident lat-lon strip workgroups "
+                         "(OGG_PASS_LL_WG, a bit-neutral tiling knob) and keep the fastest -- which count suits the write path differs "
+                         "between boxes and between the states of one box (DESIGN.md 4.1); 0: the library's default")
     ap.add_argument("--launch", default="auto", choices=["auto", "pass", "kernels"],
                     help="pass: ogg_tripolar_pass_dev (three launches, lat-lon and cap workgroups share them); kernels: one launch per "
                          "sub-grid and phase (--overlap: caps on side streams); auto: time both during set-up and keep the faster")
@@ -519,6 +523,46 @@ def main():
         sg.launch = args.launch
         if args.launch == "pass":
             use_graph = False
+    # set-up, untimed: the number of resident strip workgroups of the fused pass.  The library's defaults are the counts that won on the
+    # boxes they were swept on; the write path of another box, or of the same box ten minutes later, may prefer a neighbour (1/16 degree:
+    # 161 workgroups are 5 % faster than 72 on a box in its fast state and 8 % slower on one in its slow state).  Round-robin, two rounds
+    # of 30 passes per candidate; the knob is read when the plan is (re)built and changes no bit of the result.
+    strips_tuned = None
+    if (args.tune_strips and world == 1 and args.as_rank is None and args.latlon == "fused" and sg.launch == "pass" and not use_graph
+            and "OGG_PASS_LL_WG" not in os.environ):
+        try:
+            cands = [None, "72", "96", "108", "120", "138", "161"]
+            times = {c: [] for c in cands}
+            for rnd in range(2):
+                for c in cands:
+                    if c is None:
+                        os.environ.pop("OGG_PASS_LL_WG", None)
+                    else:
+                        os.environ["OGG_PASS_LL_WG"] = c
+                    sg.replan()
+                    for _ in range(10):
+                        sg.run_pass()
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    for _ in range(30):
+                        sg.run_pass()
+                    torch.cuda.synchronize()
+                    times[c].append((time.perf_counter() - ta) / 30 * 1e3)
+            best = min(cands, key=lambda c: min(times[c]))
+            # a neighbour must beat the default by more than a timing can be off by (1 %) to replace it
+            if best is not None and min(times[best]) > 0.99 * min(times[None]):
+                best = None
+            if best is None:
+                os.environ.pop("OGG_PASS_LL_WG", None)
+            else:
+                os.environ["OGG_PASS_LL_WG"] = best
+            sg.replan()
+            strips_tuned = {"candidates_ms": {("default" if c is None else c): [round(v, 5) for v in times[c]] for c in cands},
+                            "kept": "default" if best is None else best}
+        except Exception as exc:  # noqa: BLE001 -- never lose the bench line over the tuning: the library's default stands
+            os.environ.pop("OGG_PASS_LL_WG", None)
+            sg.replan()
+            strips_tuned = {"error": repr(exc)}
     for _ in range(args.warmup):
         sg.step()
     if use_graph:
@@ -800,7 +844,7 @@ def main():
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "cap_symmetry": args.cap_symmetry, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
                        "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
                            world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
-            "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned,
+            "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned, "autotune_strip_workgroups": strips_tuned,
             "ms_per_step_eager_with_events": dt_eager / args.steps * 1e3,
             "aggregate_GBps_at_48B_per_cell": round(48.0 * plan.cells * args.steps / dt / 1e9, 1),
             "roofline": roof, "roofline_valu": roof_valu, "pass_launches": launches,

@@ -23,7 +23,7 @@ for rnd in range(args.rounds):
     for wl in args.workloads:
         for lib in args.libs:
             env = dict(os.environ, OGG_LIB_PATH=os.path.abspath(lib))
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(args.steps), "--cpu-sample-div", "0", "--d2h", "0", "--checksum", "0", "--power-probe", "0"] + args.extra.split(),
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", str(args.steps), "--cpu-sample-div", "0", "--d2h", "0", "--checksum", "0", "--power-probe", "0", "--tune-strips", "0"] + args.extra.split(),
                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if out.returncode:
                 print(out.stderr[-2000:], flush=True)

@@ -5,7 +5,7 @@
 tag=$1; wl=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/valu_${tag}_${wl}; rm -rf $out; mkdir -p $out
-args="bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample-div 0 --self-check 0 --d2h 0 --power-probe 0 --dp-arc-other 0 --launch pass $*"
+args="bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample-div 0 --self-check 0 --d2h 0 --power-probe 0 --dp-arc-other 0 --launch pass --tune-strips 0 $*"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/a -o a --output-format csv -- python3 $args > $out/a.log 2>&1 &&
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d $out/b -o b --output-format csv -- python3 $args > $out/b.log 2>&1 &&
 rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR -d $out/c -o c --output-format csv -- python3 $args > $out/c.log 2>&1
