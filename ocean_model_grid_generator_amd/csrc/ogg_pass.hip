@@ -310,7 +310,8 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // on a fast box, 0.2397 -> 0.2158 on a slow one; 156: 0.2137), 1/16 degree 72-138 (-2 ... -3 %; 72 against 96: -1.2 % on three boxes
     // with the row table; on boxes in their fast state 138-161 are 4-5 % faster still, on the slow ones 8 % slower: 72 stays); 1/8 degree
     // with 6-row table-fed strips: 108 (nine per column tile) against 96: -3.2 % and -3.9 % on two boxes (0.1948 -> 0.1886; 120: 0.1938,
-    // 132: 0.1912), the half-grid share indifferent; with a displaced-pole quadrature in
+    // 132: 0.1912); the shares of that grid, 6-row table-fed strips, 108 against the 96 / 96 / 120 of the longer strips: a half 0.1028 ->
+    // 0.1004, a quarter 0.0534 -> 0.0508, an eighth 0.0295 -> 0.0291 (the last rank's smaller share 0.0353 -> 0.0344 at 96); with a displaced-pole quadrature in
     // the launch 48-60 and as many helpers behind the compute roles (0.3145 -> 0.286)
     if (pool < 0) pool = (int)env_long("OGG_PASS_LL_POOL", (light || points >= 16000000) ? 1 : 0);
     s.pool = pool;
@@ -319,8 +320,9 @@ LatlonShare make_share(const FusedParams& ll, long lo, long hi, long ni1, bool a
     // the 1/4 degree grid with its displaced-pole quadrature is better off with owned blocks (+1 ... +9 % pooled)
     long max_wg = alone ? 2048
                         : (points >= 16000000 ? env_long("OGG_PASS_LL_WG", pool ? (light ? (points >= 48000000 ? 72 : (table ? 108 : 96)) : (table ? 96 : 60)) : (light ? 156 : 90))
-                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", pool ? 96 : (light ? 150 : 90))
-                                                                   : env_long("OGG_PASS_LL_WG_SMALL", points >= 4000000 ? (pool ? 96 : (light ? 180 : 120)) : 120)));
+                                              : (points >= 8000000 ? env_long("OGG_PASS_LL_WG_MID", pool ? (table ? 108 : 96) : (light ? 150 : 90))
+                                                                   : env_long("OGG_PASS_LL_WG_SMALL", points >= 4000000 ? (pool ? (table ? 108 : 96) : (light ? 180 : 120))
+                                                                                                                        : ((pool && table) ? 108 : 120))));
     long gy = hi - lo;
     if (s.gx * gy > max_wg) gy = (max_wg + s.gx - 1) / s.gx;
     s.gy = gy < 1 ? 1 : gy;
