@@ -260,9 +260,27 @@ void plan_handle_life_cycle() {
     ll.x = g.data(), ll.y = ll.x + 100 * ni1, ll.dx = ll.y + 100 * ni1, ll.dy = ll.dx + 100 * ni1, ll.area = ll.dy + 100 * ni1, ll.angle = ll.area + 100 * ni1;
     for (int rep = 0; rep < 3; ++rep) {
         void* h = nullptr;
+        if (rep == 1) setenv("OGG_PASS_LL_TABLE", "0", 1);   // the strips evaluate their rows' scalars themselves: no table, no table role
+        else unsetenv("OGG_PASS_LL_TABLE");
         CHECK(ogg_supergrid_pass_plan_dev(1, &ll, ni1, -300.0, 360.0, 6371e3, 1, &cap, nullptr, &h) == OGG_OK && h, "plan: %s", ogg_last_error());
         if (!h) return;
         CHECK(ogg_supergrid_pass_plan_slots(h) == 2, "slots");
+        {   // the handle's row tables: one per slot, the plan's own, read by the strips of that slot's launch B and filled by its table roles
+            const PassPipe& H = *static_cast<const PassPipe*>(h);
+            const bool want = rep != 1;   // (rep 1 is built with OGG_PASS_LL_TABLE=0)
+            for (int k = 0; k < 2; ++k) {
+                const PassPlan& P = H.slot[k];
+                CHECK((H.own_row_tab[k] != nullptr) == want, "slot %d: row table allocated %d, wanted %d", k, H.own_row_tab[k] != nullptr, (int)want);
+                CHECK(P.B.ll.row_tab == H.own_row_tab[k] && P.A.ll.row_tab == H.own_row_tab[k], "slot %d: the launches read another table than the slot's", k);
+                CHECK(P.A.n_ll_tab == (want ? latlon_row_table_blocks(P.A.ll) : 0), "slot %d: %ld table workgroups", k, P.A.n_ll_tab);
+                CHECK(P.A.ll.row0[P.A.ll.n_bands] == ll.n_pt_rows + 1, "slot %d: %ld table rows for %ld point rows", k, P.A.ll.row0[P.A.ll.n_bands], ll.n_pt_rows);
+                CHECK(P.B.ll.rows_per_block == (want ? 6 : P.B.ll.rows_per_block) && P.A.ll.rows_per_block == P.B.ll.rows_per_block &&
+                          P.A.ll.strip0[1] == P.B.ll.strip0[1] && P.B.ll.strip0[1] == (ll.n_pt_rows + P.B.ll.rows_per_block - 1) / P.B.ll.rows_per_block,
+                      "slot %d: strips of %d rows, %ld / %ld of them", k, P.B.ll.rows_per_block, P.A.ll.strip0[1], P.B.ll.strip0[1]);
+                CHECK(P.na == (unsigned)(P.A.share.n_wg + P.A.n_tab + P.A.n_dq_tab + P.A.n_dm_reset + P.A.n_ll_tab + P.A.n_mesh), "slot %d: launch A's grid", k);
+            }
+            CHECK(H.slot[0].B.ll.row_tab != H.slot[1].B.ll.row_tab || !want, "the two slots share a row table");
+        }
         for (int k = 0; k < 5; ++k) CHECK(ogg_supergrid_pass_run_dev(h, nullptr, nullptr, nullptr) == OGG_OK, "run %d", k);
         CHECK(ogg_supergrid_pass_plan_carried_runs(h) == 4, "carried runs %ld", ogg_supergrid_pass_plan_carried_runs(h));
         int flags = -1;
