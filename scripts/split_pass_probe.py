@@ -19,7 +19,37 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="r16")
 ap.add_argument("--world", type=int, default=4)
 ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--copies", type=int, default=0, help="instead of the band shares: this many WHOLE grids with buffers of their own, each alone and then "
+                "round-robin -- between two passes over one copy the others' bytes are written (how fast is a pass that finds nothing of its "
+                "predecessor on the chip?)")
 args = ap.parse_args()
+if args.copies > 0:
+    grids = []
+    for k in range(args.copies):
+        g = supergrid.Supergrid(supergrid.SupergridPlan(**bench.WORKLOADS[args.workload]), rank=0, world=1, device="cuda:0", halo="recompute")
+        g.launch = "pass"
+        grids.append(g)
+
+    def t_of(fn, n):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def robin():
+        for g in grids:
+            g.run_pass()
+
+    for rnd in range(2):
+        alone = [t_of(g.run_pass, args.steps) for g in grids]
+        rr = t_of(robin, args.steps) / args.copies
+        print("%s, %d copies, round %d: one copy over and over %s ms per pass; round-robin over the copies %.4f ms per pass"
+              % (args.workload, args.copies, rnd, " ".join("%.4f" % a for a in alone), rr), flush=True)
+    raise SystemExit(0)
 plan1 = supergrid.SupergridPlan(**bench.WORKLOADS[args.workload])
 whole = supergrid.Supergrid(plan1, rank=0, world=1, device="cuda:0", halo="recompute")
 whole.launch = "pass"
