@@ -509,6 +509,32 @@ class Supergrid(object):
         import contextlib
         with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
             self.lon1d = torch.empty(ni1, dtype=torch.float64, device=self.device)
+            # OGG_FIELD_SLAB=<alignment in bytes> (experiment): the six fields of all bands from ONE allocation, every field at a multiple of
+            # the alignment, instead of one allocation per field
+            slab_align = int(os.environ.get("OGG_FIELD_SLAB", "0"))
+            slab, slab_off = None, 0
+            if slab_align > 0 and self.device.type == "cuda":
+                total = 0
+                for s in plan.subs:
+                    lo, hi = self.rows_of(s, rank, world)
+                    n = hi - lo
+                    n_cell = max(min(hi, s.nj1 - 1) - lo, 0)
+                    halo = 1 if (latlon == "stencil" and s.kind in ("mercator", "latlon") and n_cell > 0 and hi < s.nj1) else 0
+                    for r, c in ((n + halo, ni1), (n + halo, ni1), (n, ni1 - 1), (n_cell, ni1), (n_cell, ni1 - 1), (n, ni1)):
+                        total += (max(r, 0) * c * 8 + slab_align - 1) // slab_align * slab_align
+                slab = torch.empty(total + slab_align, dtype=torch.uint8, device=self.device)
+                slab_off = (-slab.data_ptr()) % slab_align
+                self._slab = slab
+
+            def field_buffer(r, c):
+                nonlocal slab_off
+                if slab is None:
+                    return torch.empty((max(r, 0), c), dtype=torch.float64, device=self.device)
+                nbytes = max(r, 0) * c * 8
+                t = slab[slab_off:slab_off + nbytes].view(torch.float64).view(max(r, 0), c)
+                slab_off += (nbytes + slab_align - 1) // slab_align * slab_align
+                return t
+
             for s in plan.subs:
                 lo, hi = self.rows_of(s, rank, world)
                 n = hi - lo
@@ -518,7 +544,7 @@ class Supergrid(object):
                 rows_xy = n + (1 if needs_halo else 0)
                 for f, (r, c) in (("x", (rows_xy, ni1)), ("y", (rows_xy, ni1)), ("dx", (n, ni1 - 1)), ("dy", (b["n_cell"], ni1)),
                                   ("area", (b["n_cell"], ni1 - 1)), ("angle_dx", (n, ni1))):
-                    b[f] = torch.empty((max(r, 0), c), dtype=torch.float64, device=self.device)
+                    b[f] = field_buffer(r, c)
                 if s.kind == "mercator":
                     if getattr(s, "explicit_axis", None) is not None:   # enhanced-equator axis: spliced on the host (OGG:349-428)
                         b["axis"] = torch.from_numpy(s.explicit_axis).to(self.device)
