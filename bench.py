@@ -842,6 +842,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "1/8 deg tripolar supergrid with metrics (-r 8)" if args.workload == "r8" else args.workload,
                        "flags": flags, "dp_arc": (args.dp_arc if has_dp else None), "cap_symmetry": args.cap_symmetry, "supergrid": [plan.nyp, plan.Ni + 1], "cells": plan.cells,
+                       "field_slab": getattr(sg, "field_slab", None),
                        "parallelism": "latitude bands x%d per sub-grid, latlon=%s, halo=%s" % (
                            world, args.latlon, (args.halo if (world > 1 and args.latlon == "stencil") else "none"))},
             "device": _lib.device_name(), "launch": timed_launch, "autotune_ms": tuned, "autotune_strip_workgroups": strips_tuned,

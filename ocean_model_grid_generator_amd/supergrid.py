@@ -509,22 +509,40 @@ class Supergrid(object):
         import contextlib
         with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
             self.lon1d = torch.empty(ni1, dtype=torch.float64, device=self.device)
-            # OGG_FIELD_SLAB=<alignment in bytes> (experiment): the six fields of all bands from ONE allocation, every field at a multiple of
-            # the alignment, instead of one allocation per field
-            slab_align = int(os.environ.get("OGG_FIELD_SLAB", "0"))
-            slab, slab_off = None, 0
-            if slab_align > 0 and self.device.type == "cuda":
-                total = 0
+            # Where the output arrays lie moves a write-bound pass by +-6 %: allocated one by one, the fields of a band land wherever the
+            # allocator puts them, and the 1/8 degree pass runs 0.185 or 0.21 ms by the draw (four grids in one process: 0.185 / 0.207 /
+            # 0.187 / 0.210; 1/16 degree 0.91 / 1.07).  OGG_FIELD_SLAB=<bytes> (experiment) takes the fields of all bands from ONE
+            # allocation, every field at a multiple of that many bytes: 2 GiB apart all four grids ran 0.184-0.186 on one box and one of
+            # two on another; 256 B ... 1 GiB apart no better than the draw (scripts/split_pass_probe.py --copies 4,
+            # profiles/r05_split_pass_probe.md).  Not understood, so not a default: one allocation per field.
+            def field_shapes():
                 for s in plan.subs:
                     lo, hi = self.rows_of(s, rank, world)
                     n = hi - lo
                     n_cell = max(min(hi, s.nj1 - 1) - lo, 0)
                     halo = 1 if (latlon == "stencil" and s.kind in ("mercator", "latlon") and n_cell > 0 and hi < s.nj1) else 0
                     for r, c in ((n + halo, ni1), (n + halo, ni1), (n, ni1 - 1), (n_cell, ni1), (n_cell, ni1 - 1), (n, ni1)):
-                        total += (max(r, 0) * c * 8 + slab_align - 1) // slab_align * slab_align
-                slab = torch.empty(total + slab_align, dtype=torch.uint8, device=self.device)
-                slab_off = (-slab.data_ptr()) % slab_align
-                self._slab = slab
+                        yield max(r, 0) * c * 8
+
+            slab, slab_off, slab_align = None, 0, 0
+            if self.device.type == "cuda":
+                forced = os.environ.get("OGG_FIELD_SLAB")
+                sizes = list(field_shapes())
+                if forced is not None:
+                    slab_align = int(forced)
+                if slab_align > 0:
+                    total = sum((b + slab_align - 1) // slab_align * slab_align for b in sizes) + slab_align
+                    try:
+                        free_bytes = torch.cuda.mem_get_info(self.device)[0]
+                    except Exception:  # noqa: BLE001 -- no memory information: no slab
+                        free_bytes = 0
+                    if total > free_bytes * 9 // 10:   # (several grids in one process: the later ones fall back)
+                        slab_align = 0
+                    else:
+                        slab = torch.empty(total, dtype=torch.uint8, device=self.device)
+                        slab_off = (-slab.data_ptr()) % slab_align
+                        self._slab = slab
+            self.field_slab = {"spacing_bytes": slab_align, "bytes": int(slab.numel()) if slab is not None else 0}
 
             def field_buffer(r, c):
                 nonlocal slab_off
