@@ -44,6 +44,9 @@ if args.copies > 0:
         for g in grids:
             g.run_pass()
 
+    for k, g in enumerate(grids):   # where the copy's biggest band lies (virtual addresses of its six fields, GiB)
+        big = max(g.buf.values(), key=lambda b: b["x"].numel())
+        print("copy %d: %s" % (k, " ".join("%s %.3f" % (f, big[f].data_ptr() / 2.0**30) for f in supergrid.FIELDS)), flush=True)
     for rnd in range(2):
         alone = [t_of(g.run_pass, args.steps) for g in grids]
         rr = t_of(robin, args.steps) / args.copies
